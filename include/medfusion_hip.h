@@ -1,0 +1,186 @@
+/*
+ * medfusion_hip.h -- C-ABI of libmedfusion_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the latent-diffusion SAMPLING path of mueller-franzes/medfusion
+ * (DiffusionPipeline.sample -> UNet denoise loop -> VAE.decode; VAE.encode as API surface).
+ * The reference is pure PyTorch: its "FFI" for this path is the set of ATen ops each Python
+ * method dispatches.  Every entry point below names the reference call site(s) it replaces
+ * (paths relative to the reference repo root).  The Python host (medfusion_amd/) binds these
+ * with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *    owned by the caller (torch allocations); the library never allocates, frees or retains
+ *    device memory.  Scratch is caller-provided (`*_workspace_bytes`).
+ *  - fp32 everywhere.  Activations are NHWC ("channels-last") inside the path; the API edge
+ *    tensors of the reference (latents, images) are NCHW and are read/written directly by the
+ *    edge convolutions (MF_LAYOUT_NCHW) -- no separate transpose pass.
+ *  - Every call is an asynchronous launch on `stream` (a hipStream_t passed as void*);
+ *    no host sync, no allocation, no host reads: hipGraph-capture-safe.
+ *  - Return 0 on success, negative MF_E* on failure; message via mf_last_error() (thread-local).
+ */
+#ifndef MEDFUSION_HIP_H
+#define MEDFUSION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_VERSION 100 /* 0.1.0 */
+
+enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
+enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
+
+int mf_version(void);
+const char* mf_last_error(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Replaces torch.nn.Conv2d.forward at: conv_blocks.py:185 (BasicBlock.conv), :238 (conv_res 1x1),
+ * :66 (BasicDown 3x3 stride 2), :123-125 (BasicUp: F.interpolate nearest-exact x2 + 3x3 conv, fused:
+ * upsample=1 gathers from the low-res tensor), unet2.py:259 (torch.cat([h, skip]) fused: x2/C2),
+ * unet2.py:267 / latent_embedders.py:768 (1x1 out convs).
+ * Weights are pre-packed once by mf_pack_conv_weight_f32 (OIHW -> [Cout][KH][KW][Cin]).
+ */
+typedef struct MfConvDesc {
+  int32_t N, Hin, Win;     /* batch, input spatial size (BEFORE the fused x2 upsample) */
+  int32_t C1, C2;          /* channels read from x1 and x2 (C2 = 0: single source); Cin = C1 + C2 */
+  int32_t Cout;
+  int32_t KH, KW;          /* 1x1 or 3x3 */
+  int32_t stride;          /* 1 or 2 */
+  int32_t pad;             /* MONAI get_padding(k, s) = int((k - s + 1) / 2) */
+  int32_t upsample;        /* 1: nearest x2 of the input is fused into the gather */
+  int32_t in_layout;       /* layout of x1 (NCHW only with C2 == 0) */
+  int32_t out_layout;      /* layout of y */
+  int32_t tile_hint;       /* 0 = auto; else forces an implicit-GEMM tile config (tuning/tests) */
+  int32_t splitk_hint;     /* 0 = auto; else forces split-K factor */
+  int32_t reserved;
+} MfConvDesc;
+
+int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
+/* y = conv(x1 (++ x2 on channels), w) + bias.  bias may be NULL.  workspace >= mf_conv2d_workspace_bytes. */
+int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,
+                  void* workspace, size_t workspace_bytes, const MfConvDesc* d, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm + Swish + residual + embedding
+ * Replaces nn.GroupNorm + MONAI Swish + `out + residual` + `x += emb` at conv_blocks.py:186-191,
+ * :236-240, :360-363 (UnetResBlock) / :298-301 (UnetBasicBlock).  NHWC.
+ * stats[n][g] = {mean, rstd} (biased variance, eps inside the sqrt).
+ */
+size_t mf_gn_stats_workspace_bytes(int N, int HW, int C, int G);
+int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t workspace_bytes, int N, int HW, int C, int G,
+                    float eps, void* stream);
+/* out = act(gn(x) * gamma + beta) + residual + emb[n*emb_stride + c]; act: 0 none, 1 Swish x*sigmoid(x).
+ * gamma/beta NULL => no affine; stats NULL => no normalisation; residual / emb NULL => skipped.
+ * out may alias x. */
+int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+                    const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream);
+
+/* ------------------------------------------------------------------ small dense ops
+ * mf_linear_f32: y[b*y_stride + o] = sum_i f(x[b*x_stride + i]) * w[o*In + i] + bias[o] (+ y if accumulate);
+ * f = Swish if act_in else identity.  Replaces nn.Linear at time_embedder.py:66-71 and the
+ * local_embedder Swish->Linear at conv_blocks.py:340-344,349-353 (all 17 batched into one call by the host).
+ */
+int mf_linear_f32(const float* x, int64_t x_stride, const float* w, const float* bias, float* y, int64_t y_stride,
+                  int B, int In, int Out, int act_in, int act_out, int accumulate, void* stream);
+/* SinusoidalPosEmb (time_embedder.py:15-28): out[b][0:half] = sin(t f_k), [half:2half] = cos(t f_k),
+ * f_k = exp(-(ln(max_period)/(half - shift)) k); flip swaps halves; odd dim zero-padded. */
+int mf_sinusoidal_f32(const float* t, float* out, int B, int dim, float max_period, float shift, int flip, void* stream);
+/* LabelEmbedder lookup + save_add (cond_embedders.py:19-24, conv_blocks.py:16-18): io[b][:] += table[idx[b]][:] */
+int mf_embedding_add_f32(const float* table, const int64_t* idx, float* io, int B, int D, int num_rows, void* stream);
+
+/* ------------------------------------------------------------------ scheduler step (one fused elementwise pass)
+ * Replaces the ~49 ATen ops/step of DiffusionPipeline.forward :240-273 (CFG combine, objective switch),
+ * GaussianNoiseScheduler.estimate_x_0 :119-124, estimate_x_T :127-131, estimate_mean_t :104-107,
+ * estimate_variance_t :110-116, estimate_x_t_prior_from_x_0 :85-101 and the DDIM update
+ * diffusion_pipeline.py:297-304.  Per-step scalars are computed on the host in fp32 exactly as the
+ * reference computes them and live in a device table; the step index may come from device memory so a
+ * captured hipGraph replays unchanged (no host sync, unlike the reference's `alphas_cumprod[t]`).
+ * Products are rounded separately (no FMA contraction) to mirror ATen's elementwise chain.
+ */
+typedef struct MfSchedStep {
+  float sqrt_recip_ac;    /* sqrt_recip_alphas_cumprod[t] */
+  float sqrt_recipm1_ac;  /* sqrt_recipm1_alphas_cumprod[t] */
+  float coef1, coef2;     /* posterior_mean_coef1/2[t] */
+  float std_fixed;        /* exp(0.5*log(clamp(posterior_variance[t],1e-20))), 0 when t == 0 (var_scale == 0 path) */
+  float log_var_min;      /* log(clamp(posterior_variance[t])) -- learned-variance path */
+  float log_var_max;      /* log(clamp(betas[t])) */
+  float ddim_sqrt_an;     /* sqrt(alphas_cumprod[t_next]) */
+  float ddim_c;           /* sqrt(1 - alpha_next - sigma^2) */
+  float ddim_sigma;       /* eta * sqrt((1 - a/a_next)(1 - a_next)/(1 - a)), eta == 1 */
+  int32_t t;              /* timestep value (for t == 0 test) */
+  int32_t mode;           /* 0: x_t <- x_t_prior (DDPM / last DDIM iteration); 1: DDIM update */
+} MfSchedStep;
+
+typedef struct MfSchedArgs {
+  const float* x_t;          /* [n] current latent */
+  const float* pred;         /* [n] estimator output (conditional pass when CFG) */
+  const float* pred_uncond;  /* [n] or NULL: CFG pred = pu + g*(pred - pu) */
+  const float* pred_var;     /* [n] or NULL: learned variance head (estimate_variance=True, g == 1 only) */
+  const float* noise_post;   /* base of posterior-noise bank */
+  const float* noise_ddim;   /* base of DDIM-noise bank (unused when mode == 0) */
+  int64_t noise_step_stride; /* elements between consecutive steps in the banks (0: same buffer each step) */
+  float* x_t_out;            /* [n] next latent (may alias x_t) */
+  float* x0_out;             /* [n] or NULL: x_0 estimate of this step */
+  float* xT_out;             /* [n] or NULL: x_T estimate of this step */
+  const MfSchedStep* table;  /* device table, one entry per loop iteration */
+  const int32_t* step_dev;   /* device step counter or NULL (then `step` is used) */
+  int32_t step;
+  int32_t objective;         /* 0: 'x_T', 1: 'x_0' */
+  int32_t clip_x0;           /* clamp x_0 to [-1, 1] */
+  float guidance_scale;
+  int64_t n;                 /* elements */
+} MfSchedArgs;
+int mf_sched_step_f32(const MfSchedArgs* a, void* stream);
+/* *counter += inc (one thread); lets a captured graph advance its own step index. */
+int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream);
+
+/* ------------------------------------------------------------------ noise
+ * Counter-based standard normals (Philox-4x32-10 + Box-Muller), shard-invariant: element quad q of sample
+ * (sample_offset + b) in draw `draw` depends only on (seed, draw, sample index, q).  Stands in for
+ * torch.randn_like at diffusion_pipeline.py:315(x_final), gaussian_scheduler.py:99, diffusion_pipeline.py:303.
+ * draw index = draw_base + draw_stride * step where step = *step_dev (or `step`).
+ */
+int mf_philox_normal_f32(float* out, uint64_t seed, int32_t draw_base, int32_t draw_stride, const int32_t* step_dev,
+                         int32_t step, int64_t sample_offset, int B, int64_t per_sample, void* stream);
+
+/* ------------------------------------------------------------------ attention family (use_attention = 'linear'|'spatial')
+ * mf_attention_f32: compute_attention (attention_blocks.py:35-43) on NHWC-token tensors:
+ * q [B][Nq][H*d], k,v [B][Nk][H*d] -> out [B][Nq][H*d]; softmax((q s)(k s)^T) v per head, s = d^-0.25.
+ */
+int mf_attention_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int Nq, int Nk, int d,
+                     float scale, void* stream);
+/* LayerNorm over the last dim (attention_blocks.py:22), rows x C */
+int mf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int C, float eps,
+                     void* stream);
+/* GEGLU gate (attention_blocks.py:23-24): out[r][c] = h[r][c] * gelu(h[r][C + c]), h is rows x 2C */
+int mf_geglu_f32(const float* h, float* out, int64_t rows, int C, void* stream);
+/* out = a + b (elementwise, n floats) -- the `x + out` skips of attention_blocks.py:124,193,230,287 */
+int mf_add_f32(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ layout + egress
+ * NCHW <-> NHWC for API-edge tensors and tests. */
+int mf_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, void* stream);
+int mf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, void* stream);
+/* DiagonalGaussianDistribution (latent_embedders.py:22-27): z = mean + exp(0.5*clamp(logvar,-30,20)) * noise,
+ * moments NCHW [N][2C][HW] -> z [N][C][HW] */
+int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float* z, int N, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------ built-in launch timing (bench / roofline)
+ * When enabled every launch is bracketed by hipEvents on its own stream and attributed to a kernel family.
+ * NOT capture-safe; off by default. */
+enum { MF_FAM_CONV_IGEMM = 0, MF_FAM_CONV_DIRECT, MF_FAM_SPLITK_REDUCE, MF_FAM_GN_STATS, MF_FAM_GN_APPLY, MF_FAM_LINEAR,
+       MF_FAM_SCHED, MF_FAM_NOISE, MF_FAM_ATTENTION, MF_FAM_MISC, MF_FAM_COUNT };
+int mf_prof_enable(int on);
+int mf_prof_reset(void);
+/* synchronises outstanding events; returns summed ms, launch count, algorithmic flops and bytes of a family */
+int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, double* bytes);
+const char* mf_prof_family_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDFUSION_HIP_H */

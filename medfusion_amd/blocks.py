@@ -1,0 +1,393 @@
+"""Building blocks of the UNet / VAE on the HIP kernels (host-side mirror of the reference's
+medical_diffusion/models/utils/{conv_blocks,attention_blocks}.py: same class names, constructor
+meaning and state-dict keys; spatial_dims=2 only).
+
+Modules hold their parameters in the reference layout (OIHW conv weights) so reference checkpoints
+load with `load_state_dict`; device-side packed copies ([Cout][KH][KW][Cin]) are built lazily and
+rebuilt when a parameter changes.  `forward` takes NHWC tensors [N,H,W,C] on the GPU.  An input may be
+a pair (h, skip): the channel concat of unet2.py:259 is fused into the convolutions that consume it.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import lib as L
+
+Act = Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]
+
+
+def monai_padding(kernel_size: int, stride: int) -> int:
+    """MONAI get_padding as used at conv_blocks.py:48,169,229: int((k - s + 1) / 2)."""
+    p = (kernel_size - stride + 1) / 2
+    if p < 0:
+        raise AssertionError("padding value should not be negative")
+    return int(p)
+
+
+def zero_module(m: nn.Module) -> nn.Module:
+    """attention_blocks.py:27-33"""
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+def _split(x: Act):
+    return (x[0], x[1]) if isinstance(x, (tuple, list)) else (x, None)
+
+
+class _Packed:
+    """Lazily packed device copy of a conv weight, invalidated by in-place parameter updates."""
+
+    def __init__(self):
+        self._key = None
+        self._w = None
+
+    def get(self, weight: torch.Tensor) -> torch.Tensor:
+        key = (weight.data_ptr(), weight._version, weight.device)
+        if key != self._key:
+            w = weight.detach()
+            if w.dim() == 3:  # Conv1d [O, I, 1]
+                w = w.unsqueeze(-1)
+            self._w = K.pack_conv_weight(w)
+            self._key = key
+        return self._w
+
+
+class Conv(nn.Module):
+    """Parameter holder + launcher for one convolution (nn.Conv2d replacement, never calls ATen)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, padding=0, upsample=False, conv1d=False):
+        super().__init__()
+        holder = nn.Conv1d(in_ch, out_ch, 1) if conv1d else nn.Conv2d(in_ch, out_ch, kernel_size, stride, padding, bias=True)
+        self.weight, self.bias = holder.weight, holder.bias  # default torch init, reference key names
+        self.in_ch, self.out_ch, self.k, self.stride, self.pad, self.upsample = in_ch, out_ch, kernel_size, stride, padding, int(upsample)
+        self._packed = _Packed()
+        self._descs = {}
+
+    def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None) -> torch.Tensor:
+        x1, x2 = _split(x)
+        if in_layout == L.LAYOUT_NCHW:
+            n, c1, h, w = x1.shape
+        else:
+            n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        if c1 + c2 != self.in_ch:
+            raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None)
+        d = self._descs.get(key)
+        cout = self.out_ch if rows is None else rows.stop - rows.start
+        if d is None:
+            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout)
+            self._descs[key] = d
+        wp = self._packed.get(self.weight)
+        b = self.bias
+        if rows is not None:  # output-channel slice (learned-variance head split)
+            wp, b = wp[rows], b[rows]
+        return K.conv2d(x1, wp, b, d, x2=x2, out=out)
+
+
+class GroupNorm(nn.Module):
+    """nn.GroupNorm parameter holder (keys weight/bias)."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_channels))
+            self.bias = nn.Parameter(torch.zeros(num_channels))
+        else:
+            self.weight = self.bias = None
+
+
+def _norm(norm_name, channels) -> GroupNorm:
+    kind, kw = norm_name
+    if kind.upper() != "GROUP":
+        raise NotImplementedError(f"norm {kind}: only GROUP is on the sampling path")
+    return GroupNorm(num_channels=channels, **kw)
+
+
+class BasicBlock(nn.Module):
+    """conv -> GroupNorm -> (Dropout: identity at inference) -> Swish.  conv_blocks.py:134-192."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride=1, norm_name=None, act_name=None, dropout=None,
+                 zero_conv=False):
+        super().__init__()
+        assert spatial_dims == 2
+        conv = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
+        self.conv = zero_module(conv) if zero_conv else conv
+        if norm_name is not None:
+            self.norm = _norm(norm_name, out_channels)
+        self.has_act = act_name is not None
+
+    def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC):
+        y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
+        has_norm = hasattr(self, "norm")
+        if not (has_norm or self.has_act or residual is not None or emb is not None):
+            return y
+        if out_layout != L.LAYOUT_NHWC:
+            raise RuntimeError("norm/act epilogue needs NHWC")
+        if has_norm:
+            stats = K.gn_stats(y, self.norm.num_groups, self.norm.eps)
+            return K.gn_apply(y, stats, self.norm.weight, self.norm.bias, self.norm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+        return K.gn_apply(y, None, None, None, 1, int(self.has_act), residual, emb, emb_stride, out=y)
+
+
+class BasicResBlock(nn.Module):
+    """BasicBlock(x) + (conv1x1(x) if Cin != Cout else x).  conv_blocks.py:194-240.
+    The norm/Swish/residual-add/embedding-add are one fused pass (mf_gn_apply_f32)."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride=1, norm_name=None, act_name=None, dropout=None,
+                 zero_conv=False):
+        super().__init__()
+        self.basic_block = BasicBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, act_name, dropout, zero_conv)
+        self.conv_res = Conv(in_channels, out_channels, 1, stride, monai_padding(1, stride)) if in_channels != out_channels else nn.Identity()
+
+    def forward(self, x: Act, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC):
+        if isinstance(self.conv_res, nn.Identity):
+            if isinstance(x, (tuple, list)) or in_layout != L.LAYOUT_NHWC:
+                raise RuntimeError("identity residual needs a single NHWC input")
+            res = x
+        else:
+            res = self.conv_res(x, in_layout=in_layout)
+        return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+
+
+class _EmbBlock(nn.Module):
+    BlockCls = None
+    emb_after_last = False  # UnetBasicBlock adds emb after every block (conv_blocks.py:300), UnetResBlock not after the last (:362)
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride=1, norm_name=None, act_name=None, dropout=None,
+                 emb_channels=None, blocks=2):
+        super().__init__()
+        self.out_channels = out_channels
+        self.block_seq = nn.ModuleList([
+            self.BlockCls(spatial_dims, in_channels if i == 0 else out_channels, out_channels, kernel_size, stride, norm_name, act_name,
+                          dropout, i == blocks - 1)
+            for i in range(blocks)])
+        if emb_channels is not None:
+            # Swish -> Linear(emb_channels, out_channels); index 1 carries the parameters (key `local_embedder.1.*`)
+            self.local_embedder = nn.Sequential(nn.Identity(), nn.Linear(emb_channels, out_channels))
+
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, in_layout=L.LAYOUT_NHWC):
+        """`emb`: the block's *local* embedding [B, Cout] (already through Swish->Linear; the UNet batches
+        all local embedders into one GEMM), possibly a strided view into a wider matrix."""
+        n = len(self.block_seq)
+        last = n if self.emb_after_last else n - 1
+        for i, blk in enumerate(self.block_seq):
+            e = emb if (emb is not None and i < last) else None
+            es = e.stride(0) if e is not None else 0
+            if isinstance(blk, BasicResBlock):
+                x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
+            else:
+                x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
+        return x
+
+    def local_embed(self, emb: torch.Tensor) -> torch.Tensor:
+        """Stand-alone local embedding (used when the block is driven outside a UNet)."""
+        lin = self.local_embedder[1]
+        return K.linear(emb, lin.weight, lin.bias, act_in=True)
+
+
+class UnetResBlock(_EmbBlock):
+    """conv_blocks.py:305-364"""
+    BlockCls = BasicResBlock
+    emb_after_last = False
+
+
+class UnetBasicBlock(_EmbBlock):
+    """conv_blocks.py:244-302"""
+    BlockCls = BasicBlock
+    emb_after_last = True
+
+
+class BasicDown(nn.Module):
+    """conv_blocks.py:28-70 (learnable: 3x3 stride-s conv, key `down_op.*`)."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=3, stride=2, learnable_interpolation=True, use_res=False):
+        super().__init__()
+        if not learnable_interpolation or use_res:
+            raise NotImplementedError("BasicDown: only the learnable strided conv is on the HIP path")
+        self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
+
+    def forward(self, x, emb=None):
+        return self.down_op(x)
+
+
+class BasicUp(nn.Module):
+    """conv_blocks.py:72-131: nearest-exact x2 then 3x3 conv, fused into one gather (key `up_op.*`)."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=2, stride=2, learnable_interpolation=True, use_res=False):
+        super().__init__()
+        if not learnable_interpolation or use_res:
+            raise NotImplementedError("BasicUp: only the learnable resize-conv is on the HIP path")
+        if (kernel_size, stride) != (2, 2):
+            raise NotImplementedError("BasicUp: only x2 upsampling (kernel_size=stride=2) is supported")
+        self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
+
+    def forward(self, x, emb=None):
+        return self.up_op(x)
+
+
+class SequentialEmb(nn.Sequential):
+    """conv_blocks.py:21-25 (emb is a dict here: per-module local embeddings keyed by module id)."""
+
+    def forward(self, x, emb_lookup):
+        for m in self:
+            x = m(x, emb_lookup(m))
+        return x
+
+
+# ----------------------------------------------------------------------------- attention (optional path)
+class LinearTransformer(nn.Module):
+    """attention_blocks.py:128-195.  With an embedding the cross-attention has ONE key, so softmax == 1 and
+    out = x + to_out(to_v(emb)) broadcast over space -- computed in that exact closed form."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, num_heads, ch_per_head=32, norm_name=("GROUP", {"num_groups": 32, "affine": True}),
+                 dropout=None, emb_dim=None):
+        super().__init__()
+        hid = num_heads * ch_per_head
+        self.num_heads, self.scale, self.hid = num_heads, ch_per_head ** -0.25, hid
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm_x = _norm(norm_name, in_channels)
+        self.cross = emb_dim is not None
+        emb_dim = in_channels if emb_dim is None else emb_dim
+        self.to_q = Conv(in_channels, hid, 1, conv1d=True)
+        self.to_k = Conv(emb_dim, hid, 1, conv1d=True)
+        self.to_v = Conv(emb_dim, hid, 1, conv1d=True)
+        self.to_out = nn.Sequential(zero_module(Conv(hid, out_channels, 1, conv1d=True)), nn.Identity())
+
+    def forward(self, x, embedding=None):
+        n, h, w, c = x.shape
+        if embedding is not None:
+            v = K.linear(embedding, self.to_v.weight.view(self.hid, -1), self.to_v.bias)          # [B, hid] (one key)
+            o = K.linear(v, self.to_out[0].weight.view(self.out_channels, -1), self.to_out[0].bias)  # [B, Cout]
+            if self.out_channels != c:
+                raise NotImplementedError("LinearTransformer with out_channels != in_channels")
+            return K.gn_apply(x, None, None, None, 1, 0, None, o, o.stride(0))
+        stats = K.gn_stats(x, self.norm_x.num_groups, self.norm_x.eps)
+        x_n = K.gn_apply(x, stats, self.norm_x.weight, self.norm_x.bias, self.norm_x.num_groups, 0)
+        q, k, v = self.to_q(x_n), self.to_k(x_n), self.to_v(x_n)
+        a = K.attention(q.view(n, h * w, self.hid), k.view(n, h * w, self.hid), v.view(n, h * w, self.hid), self.num_heads, self.scale)
+        out = self.to_out[0](a.view(n, h, w, self.hid))
+        return K.add(x, out, out=out) if out.shape == x.shape else out
+
+
+class GEGLU(nn.Module):
+    """attention_blocks.py:11-25"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.norm = nn.LayerNorm(in_channels)
+        self.proj = nn.Linear(in_channels, out_channels * 2, bias=True)
+        self._packed = _Packed()
+        self.out_channels = out_channels
+
+    def forward(self, x):
+        n, h, w, c = x.shape
+        xn = K.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        d = K.make_conv_desc(n, h, w, c, 0, 2 * self.out_channels, 1, 1, 0)
+        hgate = K.conv2d(xn, self._packed.get(self.proj.weight.view(2 * self.out_channels, c, 1, 1)), self.proj.bias, d)
+        return K.geglu(hgate)
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention_blocks.py:200-231"""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, num_heads, ch_per_head=32, norm_name=("GROUP", {"num_groups": 32, "affine": True}),
+                 dropout=None, emb_dim=None):
+        super().__init__()
+        self.self_atn = LinearTransformer(spatial_dims, in_channels, in_channels, num_heads, ch_per_head, norm_name, dropout, None)
+        if emb_dim is not None:
+            self.cros_atn = LinearTransformer(spatial_dims, in_channels, in_channels, num_heads, ch_per_head, norm_name, dropout, emb_dim)
+        self.proj_out = nn.Sequential(GEGLU(in_channels, in_channels * 4), nn.Identity(), Conv(in_channels * 4, out_channels, 1))
+
+    def forward(self, x, embedding=None):
+        x = self.self_atn(x)
+        if embedding is not None:
+            x = self.cros_atn(x, embedding=embedding)
+        out = self.proj_out[2](self.proj_out[0](x))
+        return K.add(out, x, out=out) if out.shape[-1] == x.shape[-1] else x
+
+
+class SpatialTransformer(nn.Module):
+    """attention_blocks.py:233-288"""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, num_heads, ch_per_head=32, norm_name=("GROUP", {"num_groups": 32, "affine": True}),
+                 dropout=None, emb_dim=None, depth=1):
+        super().__init__()
+        self.norm = _norm(norm_name, in_channels)
+        hid = num_heads * ch_per_head
+        self.proj_in = Conv(in_channels, hid, 1)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(spatial_dims, hid, hid, num_heads, ch_per_head, norm_name, dropout=dropout, emb_dim=emb_dim) for _ in range(depth)])
+        self.proj_out = Conv(hid, out_channels, 1)
+
+    def forward(self, x, embedding=None):
+        stats = K.gn_stats(x, self.norm.num_groups, self.norm.eps)
+        h = K.gn_apply(x, stats, self.norm.weight, self.norm.bias, self.norm.num_groups, 0)
+        h = self.proj_in(h)
+        for blk in self.transformer_blocks:
+            h = blk(h, embedding=embedding)
+        h = self.proj_out(h)
+        return K.add(h, x, out=h) if h.shape == x.shape else h
+
+
+class Attention(nn.Module):
+    """attention_blocks.py:291-335: 'none' -> identity, 'linear', 'spatial'."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, num_heads=8, ch_per_head=32, norm_name=("GROUP", {"num_groups": 32, "affine": True}),
+                 dropout=0, emb_dim=None, depth=1, attention_type="linear"):
+        super().__init__()
+        if attention_type == "spatial":
+            self.attention = SpatialTransformer(spatial_dims, in_channels, out_channels, num_heads, ch_per_head, norm_name, dropout, emb_dim, depth)
+        elif attention_type == "linear":
+            self.attention = LinearTransformer(spatial_dims, in_channels, out_channels, num_heads, ch_per_head, norm_name, dropout, emb_dim)
+
+    def forward(self, x, emb=None):
+        """`emb` here is the GLOBAL embedding [B, emb_dim] (time + condition), as in the reference."""
+        return self.attention(x, emb) if hasattr(self, "attention") else x
+
+
+class DownBlock(nn.Module):
+    """VAE encoder stage (conv_blocks.py:368-441)"""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, downsample_kernel_size, norm_name, act_name, dropout=None,
+                 use_res_block=False, learnable_interpolation=True, use_attention="none", emb_channels=None):
+        super().__init__()
+        enable_down = stride != 1
+        down_out = out_channels if learnable_interpolation and enable_down else in_channels
+        self.down_op = BasicDown(spatial_dims, in_channels, out_channels, downsample_kernel_size, stride, learnable_interpolation) if enable_down else nn.Identity()
+        self.attention = Attention(spatial_dims, down_out, down_out, 8, down_out // 8, norm_name, dropout, emb_channels, 1, use_attention)
+        Blk = UnetResBlock if use_res_block else UnetBasicBlock
+        self.conv_block = Blk(spatial_dims, down_out, out_channels, kernel_size, 1, norm_name, act_name, dropout, emb_channels)
+
+    def forward(self, x, emb=None):
+        x = self.down_op(x)
+        x = self.attention(x, emb)
+        return self.conv_block(x, None)
+
+
+class UpBlock(nn.Module):
+    """VAE decoder stage (conv_blocks.py:444-528)"""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, kernel_size, stride, upsample_kernel_size, norm_name, act_name, dropout=None,
+                 use_res_block=False, learnable_interpolation=True, use_attention="none", emb_channels=None, skip_channels=0):
+        super().__init__()
+        enable_up = stride != 1
+        skip_out = out_channels if learnable_interpolation and enable_up else in_channels + skip_channels
+        self.up_op = BasicUp(spatial_dims, in_channels, out_channels, upsample_kernel_size, stride, learnable_interpolation) if enable_up else nn.Identity()
+        self.attention = Attention(spatial_dims, skip_out, skip_out, 8, skip_out // 8, norm_name, dropout, emb_channels, 1, use_attention)
+        Blk = UnetResBlock if use_res_block else UnetBasicBlock
+        self.conv_block = Blk(spatial_dims, skip_out, out_channels, kernel_size, 1, norm_name, act_name, dropout, emb_channels)
+
+    def forward(self, x_enc, x_skip=None, emb=None):
+        x = self.up_op(x_enc)
+        if x_skip is not None:
+            x = K.add(x, x_skip, out=x)
+        x = self.attention(x, emb)
+        return self.conv_block(x, None)

@@ -1,0 +1,112 @@
+// api.hip -- version, thread-local error string, launch-timing registry (mf_prof_*).
+#include "common.h"
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace mf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct ProfRec {
+  int family;
+  hipEvent_t a, b;
+  double flops, bytes;
+};
+static bool g_prof = false;
+static std::mutex g_mu;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+
+bool prof_on() { return g_prof; }
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes) : idx(-1), stream(s) {
+  if (!g_prof) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfRec r{family, get_event(), get_event(), flops, bytes};
+  hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  idx = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEventRecord(g_recs[idx].b, stream);
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" {
+
+int mf_version(void) { return MF_VERSION; }
+const char* mf_last_error(void) { return g_err; }
+
+int mf_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof = on != 0;
+  return MF_OK;
+}
+
+int mf_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& r : g_recs) {
+    hipEventSynchronize(r.b);
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return MF_OK;
+}
+
+int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  double t = 0, fl = 0, by = 0;
+  int64_t n = 0;
+  for (auto& r : g_recs) {
+    if (r.family != family) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      set_error("mf_prof_query: event sync failed");
+      return MF_ELAUNCH;
+    }
+    float dt = 0;
+    hipEventElapsedTime(&dt, r.a, r.b);
+    t += dt;
+    fl += r.flops;
+    by += r.bytes;
+    ++n;
+  }
+  if (ms) *ms = t;
+  if (launches) *launches = n;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return MF_OK;
+}
+
+const char* mf_prof_family_name(int f) {
+  static const char* names[MF_FAM_COUNT] = {"conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply",
+                                            "linear", "sched", "noise", "attention", "misc"};
+  return (f >= 0 && f < MF_FAM_COUNT) ? names[f] : "?";
+}
+
+}  // extern "C"

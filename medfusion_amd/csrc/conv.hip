@@ -1,0 +1,455 @@
+// conv.hip -- 2-D convolution for the UNet / VAE of the sampling path, fp32, gfx950.
+//
+//  * conv_igemm_kernel: implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32,
+//    157 TF peak).  M = N*Hout*Wout output pixels, N = Cout, K = KH*KW*Cin ordered (tap, ci).
+//    NHWC activations make every A row of a K-chunk (32 channels of one tap) 128 contiguous bytes;
+//    weights are pre-packed [Cout][KH][KW][Cin] so B rows are contiguous too.  The gather fuses
+//    zero padding, stride 2 (BasicDown), nearest x2 upsampling (BasicUp) and the skip concat
+//    (two source pointers) -- none of those tensors is ever materialised.
+//    LDS tiles are [rows][32+4] floats: both operands are read with ds_read_b128 (4 consecutive k of
+//    one row per lane; lane>>5 selects which 4 of 8), conflict-free with the +4 pad.  The k order
+//    inside a chunk is permuted accordingly (lane half h, sub-step s <-> k = 8*kk + 4*h + s), legal
+//    because A and B use the same permutation.
+//    Register-prefetched double buffering: global loads for chunk k+1 are issued before the MFMAs of
+//    chunk k and written to the other LDS buffer after them; one barrier per chunk.
+//  * split-K (deterministic slabs + reduce kernel) fills the chip when M*Cout is small (8x8, 16x16 levels).
+//  * conv_direct_kernel: any shape / NCHW edges (Cin = 8|3, Cout = 8|3|16): <0.2 % of the FLOPs.
+#include "common.h"
+
+using namespace mf;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvP {
+  const float* x1;
+  const float* x2;
+  const float* w;
+  const float* bias;
+  float* y;
+  int N, Hin, Win, C1, C2, Cin, Cout;
+  int Hout, Wout, Heff, Weff;
+  int KH, KW, stride, pad, ups;
+  int M, K, HWout;
+  int cchunks, nk, nk_per_split, splitk;
+  int tiles_m, tiles_n;
+  long slab;
+  int in_nchw, out_nchw;
+};
+
+// bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + within;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BK = 32, LDK = BK + 4;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int RPP = NT / 8;  // staging: 8 threads (float4 each) cover one 32-float row
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BM][LDK]
+  float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int total = p.tiles_m * p.tiles_n * p.splitk;
+  const int logical = xcd_remap(blockIdx.x, total);
+  const int tile_m = logical % p.tiles_m;
+  const int rest = logical / p.tiles_m;
+  const int tile_n = rest % p.tiles_n;
+  const int kz = rest / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc_beg = kz * p.nk_per_split;
+  const int kc_end = min(p.nk, kc_beg + p.nk_per_split);
+
+  const int srow = tid >> 3, skoff = (tid & 7) * 4;
+
+  int a_n[PA], a_iy0[PA], a_ix0[PA];
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int m = m0 + q * RPP + srow;
+    if (m < p.M) {
+      const int n = m / p.HWout;
+      const int rem = m - n * p.HWout;
+      const int oy = rem / p.Wout;
+      const int ox = rem - oy * p.Wout;
+      a_n[q] = n * p.Hin;
+      a_iy0[q] = oy * p.stride - p.pad;
+      a_ix0[q] = ox * p.stride - p.pad;
+    } else {
+      a_n[q] = 0;
+      a_iy0[q] = -(1 << 28);
+      a_ix0[q] = 0;
+    }
+  }
+  const float* wbase = p.w + (long)(n0 + srow) * p.K + skoff;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tap = kc_beg / p.cchunks;
+  int cc = kc_beg - tap * p.cchunks;
+  int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  f32x4 ra[PA], rb[PB];
+
+// (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
+#define MF_GLOAD(KC)                                                                                         \
+  {                                                                                                          \
+    const int c0_ = cc * BK;                                                                                 \
+    const bool first_ = c0_ < p.C1;                                                                          \
+    const float* src_ = first_ ? p.x1 : p.x2;                                                                \
+    const int Cs_ = first_ ? p.C1 : p.C2;                                                                    \
+    const int coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                   \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                         \
+      const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;                                                      \
+      const bool ok = (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;                    \
+      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                          \
+      const long off = ((long)(a_n[q] + sy) * p.Win + sx) * Cs_ + coff_;                                     \
+      ra[q] = ok ? *reinterpret_cast<const f32x4*>(src_ + off) : f32x4{0.f, 0.f, 0.f, 0.f};               \
+    }                                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                           \
+        rb[q] = *reinterpret_cast<const f32x4*>(wbase + (long)q * RPP * p.K + (long)(KC) * BK);              \
+  }
+#define MF_ADVANCE()                      \
+  if (++cc == p.cchunks) {                \
+    cc = 0;                               \
+    if (++kx == p.KW) { kx = 0; ++ky; }   \
+  }
+#define MF_LDS_STORE(BUF)                                                                                    \
+  {                                                                                                          \
+    float* a_ = As + (BUF) * BM * LDK + srow * LDK + skoff;                                                  \
+    float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + skoff;                                                  \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra[q];    \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb[q];    \
+  }
+
+  const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
+  const float* Aw = As + (wm * TM * 32) * LDK + frag_off;
+  const float* Bw = Bs + (wn * TN * 32) * LDK + frag_off;
+
+  if (kc_beg < kc_end) {
+    MF_GLOAD(kc_beg);
+    MF_LDS_STORE(0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kc = kc_beg; kc < kc_end; ++kc) {
+    const bool has_next = kc + 1 < kc_end;
+    if (has_next) {
+      MF_ADVANCE();
+      MF_GLOAD(kc + 1);
+    }
+    const float* Ab = Aw + buf * BM * LDK;
+    const float* Bb = Bw + buf * BN * LDK;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (has_next) MF_LDS_STORE(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
+  const bool add_bias = (p.splitk == 1) && p.bias != nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const float bv = add_bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < p.M) out[(long)row * p.Cout + col] = acc[i][j][r] + bv;
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
+                                     long n4, int Cout, int splitk, long slab) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const long e = i * 4;
+    float4 s = *reinterpret_cast<const float4*>(slabs + e);
+    for (int z = 1; z < splitk; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * slab + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + (e % Cout));
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    *reinterpret_cast<float4*>(y + e) = s;
+  }
+}
+
+// one thread per output element; any channel count, either layout at either edge
+template <bool PIXEL_FAST>
+__global__ void conv_direct_kernel(const ConvP p) {
+  const long total = (long)p.M * p.Cout;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int m, co;
+  if (PIXEL_FAST) {
+    m = (int)(idx % p.M);
+    co = (int)(idx / p.M);
+  } else {
+    co = (int)(idx % p.Cout);
+    m = (int)(idx / p.Cout);
+  }
+  const int n = m / p.HWout;
+  const int rem = m - n * p.HWout;
+  const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+  float acc = p.bias ? p.bias[co] : 0.f;
+  const float* wr = p.w + (long)co * p.K;
+  for (int ky = 0; ky < p.KH; ++ky) {
+    const int iy = oy * p.stride - p.pad + ky;
+    if ((unsigned)iy >= (unsigned)p.Heff) continue;
+    const int sy = iy >> p.ups;
+    for (int kx = 0; kx < p.KW; ++kx) {
+      const int ix = ox * p.stride - p.pad + kx;
+      if ((unsigned)ix >= (unsigned)p.Weff) continue;
+      const int sx = ix >> p.ups;
+      const float* wt = wr + (ky * p.KW + kx) * p.Cin;
+      if (p.in_nchw) {
+        const float* xs = p.x1 + ((long)n * p.C1 * p.Hin + sy) * p.Win + sx;
+        const long cs = (long)p.Hin * p.Win;
+        for (int ci = 0; ci < p.C1; ++ci) acc = fmaf(xs[ci * cs], wt[ci], acc);
+      } else {
+        const float* xa = p.x1 + ((long)(n * p.Hin + sy) * p.Win + sx) * p.C1;
+        if ((p.C1 & 3) == 0) {
+          for (int ci = 0; ci < p.C1; ci += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xa + ci);
+            const float4 wv = *reinterpret_cast<const float4*>(wt + ci);
+            acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc);
+            acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+          }
+        } else {
+          for (int ci = 0; ci < p.C1; ++ci) acc = fmaf(xa[ci], wt[ci], acc);
+        }
+        if (p.C2 > 0) {
+          const float* xb = p.x2 + ((long)(n * p.Hin + sy) * p.Win + sx) * p.C2;
+          const float* wb = wt + p.C1;
+          for (int ci = 0; ci < p.C2; ++ci) acc = fmaf(xb[ci], wb[ci], acc);
+        }
+      }
+    }
+  }
+  if (p.out_nchw)
+    p.y[((long)(n * p.Cout + co) * p.Hout + oy) * p.Wout + ox] = acc;
+  else
+    p.y[(long)m * p.Cout + co] = acc;
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW) {
+  const long total = (long)Cout * Cin * KH * KW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    // o indexes packed [co][ky][kx][ci]
+    const int ci = (int)(o % Cin);
+    long t = o / Cin;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH);
+    const int co = (int)(t / KH);
+    out[o] = w[(((long)co * Cin + ci) * KH + ky) * KW + kx];
+  }
+}
+
+// ------------------------------------------------------------------ host-side planning
+struct TileCfg { int id, BM, BN, WM, WN; };
+const TileCfg kCfgs[] = {
+    {1, 128, 128, 2, 2}, {2, 128, 64, 2, 2}, {3, 64, 128, 2, 2}, {4, 64, 64, 2, 2}, {5, 128, 32, 4, 1}, {6, 64, 32, 2, 1},
+};
+
+struct Plan {
+  bool igemm;
+  TileCfg cfg;
+  int splitk, nk_per_split;
+  int Hout, Wout, Heff, Weff, M, K;
+};
+
+int fill_geometry(const MfConvDesc* d, Plan* pl) {
+  MF_REQUIRE(d != nullptr, MF_EINVAL, "conv: null desc");
+  MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
+  MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
+  MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
+  MF_REQUIRE(d->upsample == 0 || d->upsample == 1, MF_EINVAL, "conv: upsample flag");
+  MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
+  MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
+  pl->Heff = d->Hin << d->upsample;
+  pl->Weff = d->Win << d->upsample;
+  pl->Hout = (pl->Heff + 2 * d->pad - d->KH) / d->stride + 1;
+  pl->Wout = (pl->Weff + 2 * d->pad - d->KW) / d->stride + 1;
+  MF_REQUIRE(pl->Hout > 0 && pl->Wout > 0, MF_EINVAL, "conv: empty output");
+  const long M = (long)d->N * pl->Hout * pl->Wout;
+  MF_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), MF_EUNSUPPORTED, "conv: problem too large");
+  pl->M = (int)M;
+  pl->K = d->KH * d->KW * (d->C1 + d->C2);
+  return MF_OK;
+}
+
+int make_plan(const MfConvDesc* d, Plan* pl) {
+  int rc = fill_geometry(d, pl);
+  if (rc) return rc;
+  const int Cin = d->C1 + d->C2;
+  pl->igemm = d->in_layout == MF_LAYOUT_NHWC && d->out_layout == MF_LAYOUT_NHWC && (d->C1 % 32 == 0) && (d->C2 % 32 == 0) &&
+              (d->Cout % 32 == 0) && d->tile_hint >= 0;
+  pl->splitk = 1;
+  pl->nk_per_split = 0;
+  if (!pl->igemm) return MF_OK;
+  const int nk = d->KH * d->KW * (Cin / 32);
+  if (d->tile_hint > 0) {
+    const TileCfg* c = nullptr;
+    for (const auto& k : kCfgs) if (k.id == d->tile_hint) c = &k;
+    MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
+    pl->cfg = *c;
+  } else {
+    const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
+    const long t128 = (long)cdiv(pl->M, 128) * (d->Cout / BN);
+    // prefer 128-row tiles; drop to 64 rows only when even split-K cannot fill the chip
+    const int BM = (pl->M >= 128 && (t128 >= 96 || nk >= 64)) ? 128 : 64;
+    for (const auto& k : kCfgs) if (k.BM == BM && k.BN == BN) pl->cfg = k;
+  }
+  const long tiles = (long)cdiv(pl->M, pl->cfg.BM) * (d->Cout / pl->cfg.BN);
+  int sk = 1;
+  if (d->splitk_hint > 0) {
+    sk = d->splitk_hint;
+  } else {
+    // aim for >= ~2 workgroups per CU (256 CUs), keep >= 16 chunks (512 k) per split
+    while (tiles * sk < 384 && nk / (sk * 2) >= 16 && sk < 16) sk *= 2;
+  }
+  if (sk > nk) sk = nk;
+  pl->nk_per_split = cdiv(nk, sk);
+  pl->splitk = cdiv(nk, pl->nk_per_split);
+  return MF_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(const ConvP& p, hipStream_t s) {
+  constexpr int LDK = 36;
+  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int grid = p.tiles_m * p.tiles_n * p.splitk;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  return check_launch("conv_igemm");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int KH, int KW, void* stream) {
+  MF_REQUIRE(w && out && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, MF_EINVAL, "pack_conv_weight: bad args");
+  const long total = (long)Cout * Cin * KH * KW;
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * total);
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, KH, KW);
+  return check_launch("pack_conv_weight");
+}
+
+size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
+  Plan pl;
+  if (make_plan(d, &pl) != MF_OK) return 0;
+  if (!pl.igemm || pl.splitk <= 1) return 0;
+  return (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
+}
+
+int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
+                  size_t workspace_bytes, const MfConvDesc* d, void* stream) {
+  Plan pl;
+  int rc = make_plan(d, &pl);
+  if (rc) return rc;
+  MF_REQUIRE(x1 && w && y, MF_EINVAL, "conv: null pointer");
+  MF_REQUIRE(d->C2 == 0 || x2 != nullptr, MF_EINVAL, "conv: C2 > 0 but x2 is null");
+  hipStream_t s = (hipStream_t)stream;
+  ConvP p;
+  p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.y = y;
+  p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
+  p.Hout = pl.Hout; p.Wout = pl.Wout; p.Heff = pl.Heff; p.Weff = pl.Weff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.ups = d->upsample;
+  p.M = pl.M; p.K = pl.K; p.HWout = pl.Hout * pl.Wout;
+  p.in_nchw = d->in_layout == MF_LAYOUT_NCHW; p.out_nchw = d->out_layout == MF_LAYOUT_NCHW;
+  p.cchunks = p.Cin / 32; p.nk = d->KH * d->KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
+  p.tiles_m = 0; p.tiles_n = 0; p.slab = (long)pl.M * d->Cout;
+  const double flops = 2.0 * pl.M * (double)d->Cout * pl.K;
+  const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
+
+  if (!pl.igemm) {
+    ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
+    const long total = (long)pl.M * d->Cout;
+    const int blocks = (int)((total + 255) / 256);
+    if (p.out_nchw)
+      hipLaunchKernelGGL(conv_direct_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(conv_direct_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    return check_launch("conv_direct");
+  }
+
+  p.tiles_m = cdiv(pl.M, pl.cfg.BM);
+  p.tiles_n = d->Cout / pl.cfg.BN;
+  if (pl.splitk > 1) {
+    const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
+    MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv: workspace %zu < %zu", workspace_bytes, need);
+    p.y = reinterpret_cast<float*>(workspace);
+  }
+  {
+    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes);
+    switch (pl.cfg.id) {
+      case 1: rc = launch_igemm<128, 128, 2, 2>(p, s); break;
+      case 2: rc = launch_igemm<128, 64, 2, 2>(p, s); break;
+      case 3: rc = launch_igemm<64, 128, 2, 2>(p, s); break;
+      case 4: rc = launch_igemm<64, 64, 2, 2>(p, s); break;
+      case 5: rc = launch_igemm<128, 32, 4, 1>(p, s); break;
+      case 6: rc = launch_igemm<64, 32, 2, 1>(p, s); break;
+      default: set_error("conv: no tile config"); rc = MF_EINVAL;
+    }
+  }
+  if (rc) return rc;
+  if (pl.splitk > 1) {
+    const long n4 = (long)pl.M * d->Cout / 4;
+    ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
+    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4,
+                       d->Cout, pl.splitk, p.slab);
+    return check_launch("splitk_reduce");
+  }
+  return MF_OK;
+}
+
+}  // extern "C"

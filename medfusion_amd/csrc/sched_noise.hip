@@ -1,0 +1,134 @@
+// sched_noise.hip -- fused scheduler step (CFG combine + x0/xT algebra + posterior sample + DDIM update) and
+// counter-based Gaussian noise.  Pure streaming kernels over [B, C, h, w] latents (8192 floats per sample).
+#include "common.h"
+
+using namespace mf;
+
+namespace {
+
+// Every product/sum is rounded on its own (__fmul_rn/__fadd_rn block FMA contraction) so that, given
+// identical inputs, the result is bit-identical to ATen's chain of elementwise ops on CPU.
+__global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
+  const int step = a.step_dev ? *a.step_dev : a.step;
+  const MfSchedStep S = a.table[step];
+  const float* npost = a.noise_post ? a.noise_post + (long)step * a.noise_step_stride : nullptr;
+  const float* nddim = a.noise_ddim ? a.noise_ddim + (long)step * a.noise_step_stride : nullptr;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    const float xt = a.x_t[i];
+    float pred = a.pred[i];
+    if (a.pred_uncond) {  // diffusion_pipeline.py:244  pred_uncond + g * (pred_cond - pred_uncond)
+      const float pu = a.pred_uncond[i];
+      pred = __fadd_rn(pu, __fmul_rn(a.guidance_scale, __fsub_rn(pred, pu)));
+    }
+    float x0, xT;
+    if (a.objective == 0) {  // 'x_T': gaussian_scheduler.py:119-124
+      x0 = __fsub_rn(__fmul_rn(S.sqrt_recip_ac, xt), __fmul_rn(S.sqrt_recipm1_ac, pred));
+      if (a.clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+      xT = pred;
+    } else {  // 'x_0': diffusion_pipeline.py:264-267, gaussian_scheduler.py:127-131
+      x0 = a.clip_x0 ? fminf(fmaxf(pred, -1.0f), 1.0f) : pred;
+      xT = __fdiv_rn(__fsub_rn(__fmul_rn(S.sqrt_recip_ac, xt), x0), S.sqrt_recipm1_ac);
+    }
+    // posterior mean / std: gaussian_scheduler.py:95-100
+    const float mean = __fadd_rn(__fmul_rn(S.coef1, x0), __fmul_rn(S.coef2, xt));
+    float sd = S.std_fixed;
+    if (a.pred_var) {  // learned variance: var_scale = pred_var/2 + 0.5 (diffusion_pipeline.py:256), :110-116
+      const float vs = __fadd_rn(__fdiv_rn(a.pred_var[i], 2.0f), 0.5f);
+      const float lv = __fadd_rn(__fmul_rn(vs, S.log_var_max), __fmul_rn(__fsub_rn(1.0f, vs), S.log_var_min));
+      sd = S.t == 0 ? 0.0f : expf(__fmul_rn(0.5f, lv));
+    }
+    const float prior = __fadd_rn(mean, __fmul_rn(sd, npost ? npost[i] : 0.0f));
+    float xn = prior;
+    if (S.mode == 1) {  // DDIM: x_0*sqrt(a_next) + c*x_T + sigma*noise  (diffusion_pipeline.py:304)
+      xn = __fadd_rn(__fadd_rn(__fmul_rn(x0, S.ddim_sqrt_an), __fmul_rn(S.ddim_c, xT)), __fmul_rn(S.ddim_sigma, nddim ? nddim[i] : 0.0f));
+    }
+    a.x_t_out[i] = xn;
+    if (a.x0_out) a.x0_out[i] = x0;
+    if (a.xT_out) a.xT_out[i] = xT;
+  }
+}
+
+__global__ void counter_add_kernel(int32_t* c, int32_t inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
+}
+
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }  // 2^-24
+
+// one thread per quad of 4 consecutive elements of one sample (oracle/synth.py: philox_normal is the spec)
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, uint32_t seed_lo, uint32_t seed_hi, int draw_base, int draw_stride,
+                                                             const int32_t* step_dev, int step, long sample_offset, int B, long quads_per_sample) {
+  const int st = step_dev ? *step_dev : step;
+  const uint32_t draw = (uint32_t)(draw_base + draw_stride * st);
+  const long total = (long)B * quads_per_sample;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long b = i / quads_per_sample;
+    const long q = i - b * quads_per_sample;
+    uint32_t c0 = (uint32_t)q, c1 = (uint32_t)(sample_offset + b), c2 = draw, c3 = 0u;
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c0, c1, c2, c3, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    const float r0 = sqrtf(-2.0f * logf(u01(c0))), t0 = 6.283185307179586f * u01(c1);
+    const float r1 = sqrtf(-2.0f * logf(u01(c2))), t1 = 6.283185307179586f * u01(c3);
+    float s0, cs0, s1, cs1;
+    sincosf(t0, &s0, &cs0);
+    sincosf(t1, &s1, &cs1);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(r0 * cs0, r0 * s0, r1 * cs1, r1 * s1);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mf_sched_step_f32(const MfSchedArgs* a, void* stream) {
+  MF_REQUIRE(a && a->x_t && a->pred && a->x_t_out && a->table && a->n > 0, MF_EINVAL, "sched_step: bad args");
+  MF_REQUIRE(a->objective == 0 || a->objective == 1, MF_EINVAL, "sched_step: objective");
+  MF_REQUIRE(!(a->pred_var && a->pred_uncond), MF_EUNSUPPORTED,
+             "sched_step: learned variance with classifier-free guidance is unreachable in the reference (it raises)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_SCHED, s, 12.0 * a->n, 4.0 * a->n * 6);
+  long blocks = (a->n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sched_step_kernel, dim3((int)blocks), dim3(256), 0, s, *a);
+  return check_launch("sched_step");
+}
+
+int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream) {
+  MF_REQUIRE(counter, MF_EINVAL, "counter_add: null");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, inc);
+  return check_launch("counter_add");
+}
+
+int mf_philox_normal_f32(float* out, uint64_t seed, int32_t draw_base, int32_t draw_stride, const int32_t* step_dev, int32_t step,
+                         int64_t sample_offset, int B, int64_t per_sample, void* stream) {
+  MF_REQUIRE(out && B > 0 && per_sample > 0, MF_EINVAL, "philox_normal: bad args");
+  MF_REQUIRE(per_sample % 4 == 0, MF_EUNSUPPORTED, "philox_normal: per_sample must be a multiple of 4");
+  MF_REQUIRE(((uintptr_t)out & 15) == 0, MF_EINVAL, "philox_normal: out must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long quads = per_sample / 4;
+  const long total = (long)B * quads;
+  ProfScope ps(MF_FAM_NOISE, s, 100.0 * total, 16.0 * total);
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((int)blocks), dim3(256), 0, s, out, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), draw_base,
+                     draw_stride, step_dev, step, (long)sample_offset, B, quads);
+  return check_launch("philox_normal");
+}
+
+}  // extern "C"

@@ -1,0 +1,248 @@
+"""Tensor-level wrappers over the C-ABI.  torch is plumbing only: device memory, streams.
+
+Activations inside the path are NHWC torch tensors of shape [N, H, W, C] (contiguous).  Every wrapper
+launches on torch's current stream and raises if a tensor is not on the GPU -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("medfusion_amd: tensors must live on a ROCm device -- the product path has no CPU fallback")
+        if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+            raise RuntimeError(f"medfusion_amd: unsupported dtype {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Grow-only scratch owned by torch (the library never allocates).  One per device; launches on one
+    stream are serialised so sharing is safe.  Grown only outside graph capture (warm-up run does it)."""
+
+    _bufs = {}
+
+    @classmethod
+    def get(cls, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("medfusion_amd: workspace growth during graph capture; run one eager warm-up first")
+            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
+def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW -> [Cout][KH][KW][Cin] (device, once at load)."""
+    _gpu(w_oihw)
+    w = w_oihw.contiguous()
+    co, ci, kh, kw = w.shape
+    out = torch.empty((co, kh, kw, ci), dtype=torch.float32, device=w.device)
+    L.check(L.load().mf_pack_conv_weight_f32(w.data_ptr(), out.data_ptr(), co, ci, kh, kw, stream()), "mf_pack_conv_weight_f32")
+    return out
+
+
+def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,
+                   tile_hint=0, splitk_hint=0) -> L.MfConvDesc:
+    return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, 0)
+
+
+def conv_out_hw(d: L.MfConvDesc):
+    he, we = d.Hin << d.upsample, d.Win << d.upsample
+    return (he + 2 * d.pad - d.KH) // d.stride + 1, (we + 2 * d.pad - d.KW) // d.stride + 1
+
+
+def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = conv(x1 ++ x2) + bias per descriptor `d`.  Output NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
+    _gpu(x1, x2, w_packed, bias)
+    lib = L.load()
+    ho, wo = conv_out_hw(d)
+    if out is None:
+        shape = (d.N, d.Cout, ho, wo) if d.out_layout == L.LAYOUT_NCHW else (d.N, ho, wo, d.Cout)
+        out = torch.empty(shape, dtype=torch.float32, device=x1.device)
+    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
+    ws = Workspace.get(need, x1.device) if need else None
+    rc = lib.mf_conv2d_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, C.byref(d), stream())
+    L.check(rc, "mf_conv2d_f32")
+    return out
+
+
+def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
+    """x NHWC [N,H,W,C] -> stats [N,G,2] = (mean, rstd)."""
+    _gpu(x)
+    n, h, w, c = x.shape
+    lib = L.load()
+    stats = torch.empty((n, G, 2), dtype=torch.float32, device=x.device)
+    need = lib.mf_gn_stats_workspace_bytes(n, h * w, c, G)
+    ws = Workspace.get(need, x.device)
+    L.check(lib.mf_gn_stats_f32(x.data_ptr(), stats.data_ptr(), ws.data_ptr(), need, n, h * w, c, G, eps, stream()), "mf_gn_stats_f32")
+    return stats
+
+
+def gn_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
+             emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(x, stats, gamma, beta, residual, emb)
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = L.load().mf_gn_apply_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
+                                  n, h * w, c, G, act, stream())
+    L.check(rc, "mf_gn_apply_f32")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_in: bool = False, act_out: bool = False,
+           out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """x [B, In] (row stride may exceed In), w [Out, In] -> [B, Out]."""
+    _gpu(x, w, bias)
+    b, inn = x.shape
+    o = w.shape[0]
+    assert w.shape[1] == inn and x.stride(1) == 1 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((b, o), dtype=torch.float32, device=x.device)
+    rc = L.load().mf_linear_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0), b, inn, o, int(act_in),
+                                int(act_out), int(accumulate), stream())
+    L.check(rc, "mf_linear_f32")
+    return out
+
+
+def sinusoidal(t: torch.Tensor, dim: int, max_period: float = 10000.0, shift: float = 1.0, flip: bool = False) -> torch.Tensor:
+    _gpu(t)
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    L.check(L.load().mf_sinusoidal_f32(t.data_ptr(), out.data_ptr(), t.shape[0], dim, max_period, shift, int(flip), stream()), "mf_sinusoidal_f32")
+    return out
+
+
+def embedding_add(table: torch.Tensor, idx: torch.Tensor, io: torch.Tensor) -> torch.Tensor:
+    _gpu(table, idx, io)
+    idx = idx.to(torch.int64).contiguous()
+    L.check(L.load().mf_embedding_add_f32(table.data_ptr(), idx.data_ptr(), io.data_ptr(), io.shape[0], io.shape[1], table.shape[0], stream()),
+            "mf_embedding_add_f32")
+    return io
+
+
+def philox_normal(out: torch.Tensor, seed: int, draw: int, sample_offset: int = 0, step_dev: Optional[torch.Tensor] = None,
+                  draw_stride: int = 0) -> torch.Tensor:
+    """Fill out [B, ...] with N(0,1): draw index = draw + draw_stride * (*step_dev or 0)."""
+    _gpu(out, step_dev)
+    b = out.shape[0]
+    per = out.numel() // b
+    rc = L.load().mf_philox_normal_f32(out.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, draw, draw_stride, _ptr(step_dev), 0, sample_offset, b, per, stream())
+    L.check(rc, "mf_philox_normal_f32")
+    return out
+
+
+def sched_step(args: L.MfSchedArgs) -> None:
+    L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
+
+
+def counter_add(counter: torch.Tensor, inc: int = 1) -> None:
+    _gpu(counter)
+    L.check(L.load().mf_counter_add_i32(counter.data_ptr(), inc, stream()), "mf_counter_add_i32")
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """q [B,Nq,C], k/v [B,Nk,C] -> [B,Nq,C]."""
+    _gpu(q, k, v)
+    b, nq, c = q.shape
+    nk = k.shape[1]
+    out = torch.empty_like(q)
+    L.check(L.load().mf_attention_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), b, heads, nq, nk, c // heads, scale, stream()),
+            "mf_attention_f32")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float = 1e-5) -> torch.Tensor:
+    _gpu(x, gamma, beta)
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(L.load().mf_layernorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.numel() // c, c, eps, stream()), "mf_layernorm_f32")
+    return out
+
+
+def geglu(h: torch.Tensor) -> torch.Tensor:
+    _gpu(h)
+    c = h.shape[-1] // 2
+    out = torch.empty((*h.shape[:-1], c), dtype=torch.float32, device=h.device)
+    L.check(L.load().mf_geglu_f32(h.data_ptr(), out.data_ptr(), h.numel() // (2 * c), c, stream()), "mf_geglu_f32")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(a, b)
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().mf_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream()), "mf_add_f32")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _gpu(x)
+    n, c, h, w = x.shape
+    x = x.contiguous()
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_nchw_to_nhwc_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, stream()), "mf_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _gpu(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_nhwc_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, stream()), "mf_nhwc_to_nchw_f32")
+    return out
+
+
+def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    _gpu(moments_nchw, noise)
+    n, c2, h, w = moments_nchw.shape
+    z = torch.empty((n, c2 // 2, h, w), dtype=torch.float32, device=moments_nchw.device)
+    L.check(L.load().mf_diag_gaussian_sample_f32(moments_nchw.data_ptr(), noise.data_ptr(), z.data_ptr(), n, c2 // 2, h * w, stream()),
+            "mf_diag_gaussian_sample_f32")
+    return z
+
+
+# ----------------------------------------------------------------------------- launch timing
+class prof:
+    """with prof() as p: ...; p.table() -> {family: (ms, launches, flops, bytes)}"""
+
+    def __enter__(self):
+        lib = L.load()
+        lib.mf_prof_reset()
+        lib.mf_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        L.load().mf_prof_enable(0)
+        return False
+
+    @staticmethod
+    def table() -> dict:
+        lib = L.load()
+        out = {}
+        for i, name in enumerate(L.FAMILIES):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            L.check(lib.mf_prof_query(i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "mf_prof_query")
+            if n.value:
+                out[name] = (ms.value, n.value, fl.value, by.value)
+        return out

@@ -1,0 +1,106 @@
+"""ctypes binding of libmedfusion_hip.so (see include/medfusion_hip.h).
+
+The product path has NO CPU fallback: if the library is missing it is built with hipcc, and if
+that fails (or a tensor is not on a ROCm device) a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "libmedfusion_hip.so"
+
+c_fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class MfConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "Hin", "Win", "C1", "C2", "Cout", "KH", "KW", "stride", "pad", "upsample", "in_layout", "out_layout",
+        "tile_hint", "splitk_hint", "reserved")]
+
+
+class MfSchedStep(C.Structure):
+    _fields_ = [("sqrt_recip_ac", C.c_float), ("sqrt_recipm1_ac", C.c_float), ("coef1", C.c_float), ("coef2", C.c_float),
+                ("std_fixed", C.c_float), ("log_var_min", C.c_float), ("log_var_max", C.c_float), ("ddim_sqrt_an", C.c_float),
+                ("ddim_c", C.c_float), ("ddim_sigma", C.c_float), ("t", C.c_int32), ("mode", C.c_int32)]
+
+
+class MfSchedArgs(C.Structure):
+    _fields_ = [("x_t", c_fp), ("pred", c_fp), ("pred_uncond", c_fp), ("pred_var", c_fp), ("noise_post", c_fp), ("noise_ddim", c_fp),
+                ("noise_step_stride", C.c_int64), ("x_t_out", c_fp), ("x0_out", c_fp), ("xT_out", c_fp), ("table", c_fp),
+                ("step_dev", c_fp), ("step", C.c_int32), ("objective", C.c_int32), ("clip_x0", C.c_int32),
+                ("guidance_scale", C.c_float), ("n", C.c_int64)]
+
+
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc")
+
+_I, _I64, _F, _SZ, _U64 = C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+_SIGS = {
+    "mf_version": (C.c_int, []),
+    "mf_last_error": (C.c_char_p, []),
+    "mf_pack_conv_weight_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, C.POINTER(MfConvDesc), c_fp]),
+    "mf_gn_stats_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "mf_gn_stats_f32": (_I, [c_fp, c_fp, c_fp, _SZ, _I, _I, _I, _I, _F, c_fp]),
+    "mf_gn_apply_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I64, c_fp, _I, _I, _I, _I, _I, c_fp]),
+    "mf_linear_f32": (_I, [c_fp, _I64, c_fp, c_fp, c_fp, _I64, _I, _I, _I, _I, _I, _I, c_fp]),
+    "mf_sinusoidal_f32": (_I, [c_fp, c_fp, _I, _I, _F, _F, _I, c_fp]),
+    "mf_embedding_add_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
+    "mf_sched_step_f32": (_I, [C.POINTER(MfSchedArgs), c_fp]),
+    "mf_counter_add_i32": (_I, [c_fp, C.c_int32, c_fp]),
+    "mf_philox_normal_f32": (_I, [c_fp, _U64, C.c_int32, C.c_int32, c_fp, C.c_int32, _I64, _I, _I64, c_fp]),
+    "mf_attention_f32": (_I, [c_fp, c_fp, c_fp, c_fp, _I, _I, _I, _I, _I, _F, c_fp]),
+    "mf_layernorm_f32": (_I, [c_fp, c_fp, c_fp, c_fp, _I64, _I, _F, c_fp]),
+    "mf_geglu_f32": (_I, [c_fp, c_fp, _I64, _I, c_fp]),
+    "mf_add_f32": (_I, [c_fp, c_fp, c_fp, _I64, c_fp]),
+    "mf_nchw_to_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_nhwc_to_nchw_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_diag_gaussian_sample_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
+    "mf_prof_enable": (_I, [_I]),
+    "mf_prof_reset": (_I, []),
+    "mf_prof_query": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "mf_prof_family_name": (C.c_char_p, [_I]),
+}
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if needed) the HIP library.  Raises RuntimeError -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        try:
+            from . import build as _build
+
+            if _build.needs_build():
+                _build.build(verbose=bool(os.environ.get("MEDFUSION_VERBOSE_BUILD")))
+        except Exception as e:  # hipcc missing etc. -- fine if a prebuilt .so travelled with the tree
+            if not LIB_PATH.exists():
+                raise RuntimeError(f"libmedfusion_hip.so is missing and could not be built: {e}") from e
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m medfusion_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().mf_last_error().decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def exported_symbols():
+    return sorted(_SIGS)

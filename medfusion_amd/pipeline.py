@@ -1,0 +1,202 @@
+"""DiffusionPipeline (sampling half) on the HIP kernels -- mirror of
+medical_diffusion/models/pipelines/diffusion_pipeline.py: ctor :20-74, forward :232-275, denoise :278-310,
+sample :312-317, interpolate :320-332.  Same signatures, keyword names, quirks (Q1-Q17) and state-dict
+prefixes (`noise_estimator.`, `noise_scheduler.`, `latent_embedder.`, `ema_model.averaged_model.`).
+
+Differences, all outside the arithmetic: no streamlit/tqdm (Q16); noise comes from a NoiseSource
+(`noise=` keyword; default = device Philox keyed by torch.initial_seed(), so `torch.manual_seed(0)` before
+`sample()` is reproducible like the reference harness); `shard=(rank, world)` keyword partitions the batch
+rows across GPUs with shard-invariant noise.  Training (`_step`) is out of scope.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import lib as L
+from .noise import NoiseSource, default_noise
+from .scheduler import GaussianNoiseScheduler
+
+
+class EMAModel(nn.Module):
+    """Inference view of utils/train_utils.py:5-88: only `averaged_model` is read (diffusion_pipeline.py:234-235)."""
+
+    def __init__(self, model, **_kw):
+        super().__init__()
+        self.averaged_model = copy.deepcopy(model).eval()
+        self.averaged_model.requires_grad_(False)
+
+
+class DiffusionPipeline(nn.Module):
+    def __init__(self, noise_scheduler, noise_estimator, latent_embedder=None, noise_scheduler_kwargs={}, noise_estimator_kwargs={},
+                 latent_embedder_checkpoint="", estimator_objective="x_T", estimate_variance=False, use_self_conditioning=False,
+                 classifier_free_guidance_dropout=0.5, num_samples=4, do_input_centering=True, clip_x0=True, use_ema=False, ema_kwargs={},
+                 **_training_only):
+        super().__init__()
+        ne_kwargs = dict(noise_estimator_kwargs)  # the reference mutates the caller's dict (:50-51); we do not
+        ne_kwargs["estimate_variance"] = estimate_variance
+        ne_kwargs["use_self_conditioning"] = use_self_conditioning
+        # classes + kwargs like the reference, or ready-made instances
+        self.noise_scheduler = noise_scheduler(**dict(noise_scheduler_kwargs)) if isinstance(noise_scheduler, type) else noise_scheduler
+        self.noise_estimator = noise_estimator(**ne_kwargs) if isinstance(noise_estimator, type) else noise_estimator
+        if latent_embedder is None:
+            self.latent_embedder = None
+        elif isinstance(latent_embedder, type):
+            from .checkpoint import load_module_from_checkpoint
+
+            self.latent_embedder = load_module_from_checkpoint(latent_embedder, latent_embedder_checkpoint)
+        else:
+            self.latent_embedder = latent_embedder
+        if self.latent_embedder is not None:
+            for p in self.latent_embedder.parameters():
+                p.requires_grad = False
+        self.estimator_objective = estimator_objective
+        self.use_self_conditioning = use_self_conditioning
+        self.num_samples = num_samples
+        self.classifier_free_guidance_dropout = classifier_free_guidance_dropout
+        self.do_input_centering = do_input_centering
+        self.estimate_variance = estimate_variance
+        self.clip_x0 = clip_x0
+        self.use_ema = use_ema
+        if use_ema:
+            self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location=None, **overrides):
+        from .checkpoint import load_pipeline_from_checkpoint
+
+        return load_pipeline_from_checkpoint(cls, path, map_location=map_location, **overrides)
+
+    # ------------------------------------------------------------------ one denoise iteration
+    def _estimator(self):
+        return self.ema_model.averaged_model if self.use_ema else self.noise_estimator
+
+    def _predict(self, x_t, t, condition, self_cond, guidance_scale, un_cond):
+        """UNet call(s) of forward :240-253.  Returns (pred, pred_uncond|None, pred_var|None)."""
+        est = self._estimator()
+        cfg = (condition is not None) and (guidance_scale != 1.0)
+        if cfg:
+            if self.estimate_variance:
+                raise RuntimeError("estimate_variance with guidance_scale != 1 raises in the reference too "
+                                   "(diffusion_pipeline.py:243-249 never chunks `pred`); use guidance_scale=1")
+            pred_uncond, _ = est(x_t, t, condition=un_cond, self_cond=self_cond)  # un-guided pass FIRST (Q6)
+            pred_cond, _ = est(x_t, t, condition=condition, self_cond=self_cond)
+            return pred_cond, pred_uncond, None
+        if self.estimate_variance:
+            pred, pred_var = est.forward_split(x_t, t, condition=condition, self_cond=self_cond)
+            return pred, None, pred_var
+        pred, _ = est(x_t, t, condition=condition, self_cond=self_cond)
+        return pred, None, None
+
+    @torch.no_grad()
+    def forward(self, x_t, t, condition=None, self_cond=None, guidance_scale=1.0, cold_diffusion=False, un_cond=None, noise=None):
+        """One reverse step like diffusion_pipeline.py:232-275 -> (x_t_prior, x_0, x_T, self_cond).
+        `noise`: the posterior draw of gaussian_scheduler.py:99 (tensor); N(0,1) from the default source if None."""
+        if cold_diffusion:
+            raise NotImplementedError("cold_diffusion is off the sampling path (SURVEY §8a S2)")
+        if self.estimator_objective not in ("x_T", "x_0"):
+            raise ValueError("Unknown Objective")
+        sch = self.noise_scheduler
+        pred, pred_uncond, pred_var = self._predict(x_t, t, condition, self_cond, guidance_scale, un_cond)
+        rec = sch.step_records([sch._uniform_t(t)], use_ddim=False)[0]
+        table = sch.upload_records([rec], x_t.device)
+        if noise is None:
+            src = default_noise()
+            src.begin(x_t.shape[0], x_t.device)
+            noise = src.draw(tuple(x_t.shape))
+        x_t = x_t.contiguous()
+        prior, x0, xT = torch.empty_like(x_t), torch.empty_like(x_t), torch.empty_like(x_t)
+        a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
+                          None if pred_var is None else pred_var.data_ptr(), noise.data_ptr(), None, 0, prior.data_ptr(), x0.data_ptr(),
+                          xT.data_ptr(), table.data_ptr(), None, 0, 0 if self.estimator_objective == "x_T" else 1, int(bool(self.clip_x0)),
+                          float(guidance_scale), x_t.numel())
+        K.sched_step(a)
+        self_cond = x0 if self.estimator_objective == "x_T" else xT
+        return prior, x0, xT, self_cond
+
+    # ------------------------------------------------------------------ the loop
+    @torch.no_grad()
+    def denoise(self, x_t, steps=None, condition=None, use_ddim=True, noise: Optional[NoiseSource] = None, trace=None, decode=True, **kwargs):
+        """diffusion_pipeline.py:278-310.  kwargs: guidance_scale, un_cond, cold_diffusion (forwarded to forward()
+        by the reference); `eta` raises like the reference's forward() would (Q2)."""
+        if "eta" in kwargs:
+            raise TypeError("forward() got an unexpected keyword argument 'eta'")
+        guidance_scale = kwargs.pop("guidance_scale", 1.0)
+        un_cond = kwargs.pop("un_cond", None)
+        if kwargs.pop("cold_diffusion", False):
+            raise NotImplementedError("cold_diffusion is off the sampling path")
+        if kwargs:
+            raise TypeError(f"forward() got an unexpected keyword argument '{next(iter(kwargs))}'")
+        if self.estimator_objective not in ("x_T", "x_0"):
+            raise ValueError("Unknown Objective")
+        if not x_t.is_cuda:
+            raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
+        sch = self.noise_scheduler
+        dev = x_t.device
+        B = x_t.shape[0]
+        timesteps, steps = sch.loop_timesteps(steps, use_ddim)
+        recs = sch.step_records(timesteps, use_ddim)
+        table = sch.upload_records(recs, dev)
+        if noise is None:  # x_t supplied by the caller (interpolate): fresh source, draws start at 0
+            noise = default_noise()
+            noise.begin(B, dev)
+        rev = list(reversed(timesteps))
+        t_all = torch.tensor(rev, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, B).contiguous()  # t.expand(B) per iteration (Q7)
+        objective = 0 if self.estimator_objective == "x_T" else 1
+        x_t = x_t.contiguous().clone()
+        n_post = torch.empty_like(x_t)
+        n_ddim = torch.empty_like(x_t)
+        x0 = torch.empty_like(x_t)
+        self_cond = None
+        for i in range(len(rev)):
+            pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond)
+            noise.draw(tuple(x_t.shape), out=n_post)          # gaussian_scheduler.py:99 -- drawn on every iteration (Q3)
+            ddim = recs[i].mode == 1
+            if ddim:
+                noise.draw(tuple(x_t.shape), out=n_ddim)      # diffusion_pipeline.py:303
+            a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
+                              None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if ddim else None, 0,
+                              x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), None, i, objective, int(bool(self.clip_x0)),
+                              float(guidance_scale), x_t.numel())
+            K.sched_step(a)
+            self_cond = x0 if self.use_self_conditioning else None  # only None-ness matters downstream (Q11)
+            if trace is not None:
+                trace.append((x0.clone(), x_t.clone()))
+        if decode and self.latent_embedder is not None:
+            x_t = self.latent_embedder.decode(x_t)
+        return x_t
+
+    @torch.no_grad()
+    def sample(self, num_samples, img_size, condition=None, noise: Optional[NoiseSource] = None, shard=None, **kwargs):
+        """diffusion_pipeline.py:312-317.  `shard=(rank, world)`: this process generates rows
+        [rank*num_samples/world, (rank+1)*num_samples/world) of the global batch (condition/un_cond are global)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("medfusion_amd.DiffusionPipeline.sample: move the pipeline to a ROCm device first (no CPU fallback)")
+        lo, hi = 0, num_samples
+        if shard is not None:
+            from .dist import shard_rows
+
+            lo, hi = shard_rows(num_samples, shard[0], shard[1])
+            if condition is not None:
+                condition = condition[lo:hi]
+            if kwargs.get("un_cond") is not None:
+                kwargs["un_cond"] = kwargs["un_cond"][lo:hi]
+        if noise is None:
+            noise = default_noise()
+        noise.begin(hi - lo, dev, sample_offset=lo, global_batch=num_samples)
+        x_T = noise.draw((hi - lo, *img_size))  # noise_scheduler.x_final(template): draw #0 (Q3)
+        return self.denoise(x_T, condition=condition, noise=noise, **kwargs)
+
+    @torch.no_grad()
+    def interpolate(self, img1, img2, i=None, condition=None, lam=0.5, **kwargs):
+        """diffusion_pipeline.py:320-332 (note: passes `i` positionally as `steps`, as the reference does)."""
+        raise NotImplementedError("interpolate needs estimate_x_t (training-side forward diffusion): SURVEY §8f row 3, not built yet")

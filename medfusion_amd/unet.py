@@ -1,0 +1,218 @@
+"""UNet noise estimator on the HIP kernels -- mirror of medical_diffusion/models/estimators/unet2.py:15-269
+(the exported `UNet`) and of the embedders in models/embedders/{time_embedder,cond_embedders}.py.
+Same constructor arguments, `forward(x_t, t, condition, self_cond) -> (y, y_ver)` and state-dict keys.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from . import lib as L
+from .blocks import (Attention, BasicBlock, BasicDown, BasicUp, Conv, SequentialEmb, UnetBasicBlock, UnetResBlock, _EmbBlock, zero_module)
+
+
+class SinusoidalPosEmb(nn.Module):
+    """time_embedder.py:7-28"""
+
+    def __init__(self, emb_dim=16, downscale_freq_shift=1, max_period=10000, flip_sin_to_cos=False):
+        super().__init__()
+        self.emb_dim, self.downscale_freq_shift, self.max_period, self.flip_sin_to_cos = emb_dim, downscale_freq_shift, max_period, flip_sin_to_cos
+
+    def forward(self, x):
+        return K.sinusoidal(x, self.emb_dim, float(self.max_period), float(self.downscale_freq_shift), self.flip_sin_to_cos)
+
+
+class TimeEmbbeding(nn.Module):
+    """time_embedder.py:52-75: sinusoid(emb_dim//4) -> Linear -> Swish -> Linear (keys time_emb.1.*, time_emb.3.*)."""
+
+    def __init__(self, emb_dim=64, pos_embedder=SinusoidalPosEmb, pos_embedder_kwargs=None, act_name=("SWISH", {})):
+        super().__init__()
+        kw = dict(pos_embedder_kwargs or {})  # fresh dict: the reference mutates a shared default (SURVEY §8c trap)
+        self.emb_dim = emb_dim
+        self.pos_emb_dim = kw.get("emb_dim", emb_dim // 4)
+        kw["emb_dim"] = self.pos_emb_dim
+        self.pos_embedder = pos_embedder(**kw)
+        self.time_emb = nn.Sequential(self.pos_embedder, nn.Linear(self.pos_emb_dim, emb_dim), nn.Identity(), nn.Linear(emb_dim, emb_dim))
+
+    def forward(self, time):
+        s = self.pos_embedder(time)
+        l1, l2 = self.time_emb[1], self.time_emb[3]
+        h = K.linear(s, l1.weight, l1.bias, act_out=True)
+        return K.linear(h, l2.weight, l2.bias)
+
+
+class LabelEmbedder(nn.Module):
+    """cond_embedders.py:6-24"""
+
+    def __init__(self, emb_dim=32, num_classes=2, act_name=("SWISH", {})):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.embedding = nn.Embedding(num_classes, emb_dim)
+
+    def forward(self, condition):
+        out = torch.zeros((condition.shape[0], self.emb_dim), dtype=torch.float32, device=condition.device)
+        return K.embedding_add(self.embedding.weight, condition, out)
+
+
+class UnetOutBlock(nn.Module):
+    """MONAI UnetOutBlock as used at unet2.py:213,217: 1x1 conv, keys `.conv.conv.{weight,bias}`."""
+
+    def __init__(self, spatial_dims, in_channels, out_channels, dropout=None):
+        super().__init__()
+        inner = nn.Sequential()
+        inner.add_module("conv", Conv(in_channels, out_channels, 1, 1, 0))
+        self.conv = inner
+
+    def forward(self, x, out_layout=L.LAYOUT_NCHW, rows=None):
+        return self.conv.conv(x, out_layout=out_layout, rows=rows)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_ch=1, out_ch=1, spatial_dims=3, hid_chs=[256, 256, 512, 1024], kernel_sizes=[3, 3, 3, 3], strides=[1, 2, 2, 2],
+                 act_name=("SWISH", {}), norm_name=("GROUP", {"num_groups": 32, "affine": True}), time_embedder=TimeEmbbeding,
+                 time_embedder_kwargs={}, cond_embedder=None, cond_embedder_kwargs={}, deep_supervision=True, use_res_block=True,
+                 estimate_variance=False, use_self_conditioning=False, dropout=0.0, learnable_interpolation=True, use_attention="none",
+                 num_res_blocks=2):
+        super().__init__()
+        if spatial_dims != 2:
+            raise NotImplementedError("the HIP sampling path is 2-D (published Medfusion models are spatial_dims=2)")
+        if act_name[0].upper() != "SWISH":
+            raise NotImplementedError("only the Swish activation is on the HIP path")
+        use_attention = use_attention if isinstance(use_attention, list) else [use_attention] * len(strides)
+        self.use_self_conditioning, self.use_res_block = use_self_conditioning, use_res_block
+        self.depth, self.num_res_blocks = len(strides), num_res_blocks
+        self.out_ch, self.estimate_variance = out_ch, estimate_variance
+
+        self.time_embedder = time_embedder(**dict(time_embedder_kwargs)) if time_embedder is not None else None
+        time_emb_dim = self.time_embedder.emb_dim if self.time_embedder is not None else None
+        self.cond_embedder = cond_embedder(**dict(cond_embedder_kwargs)) if cond_embedder is not None else None
+
+        ConvBlock = UnetResBlock if use_res_block else UnetBasicBlock
+        in_ch = in_ch * 2 if use_self_conditioning else in_ch
+        self.in_conv = BasicBlock(spatial_dims, in_ch, hid_chs[0], kernel_size=kernel_sizes[0], stride=strides[0])
+
+        def att(ch, lvl):
+            return Attention(spatial_dims, ch, ch, 8, ch // 8, norm_name, dropout, time_emb_dim, 1, use_attention[lvl])
+
+        in_blocks = []
+        for i in range(1, self.depth):
+            for k in range(num_res_blocks):
+                in_blocks.append(SequentialEmb(
+                    ConvBlock(spatial_dims, hid_chs[i - 1 if k == 0 else i], hid_chs[i], kernel_sizes[i], 1, norm_name, act_name, dropout, time_emb_dim),
+                    att(hid_chs[i], i)))
+            if i < self.depth - 1:
+                in_blocks.append(BasicDown(spatial_dims, hid_chs[i], hid_chs[i], kernel_sizes[i], strides[i], learnable_interpolation))
+        self.in_blocks = nn.ModuleList(in_blocks)
+
+        self.middle_block = SequentialEmb(
+            ConvBlock(spatial_dims, hid_chs[-1], hid_chs[-1], kernel_sizes[-1], 1, norm_name, act_name, dropout, time_emb_dim),
+            att(hid_chs[-1], -1),
+            ConvBlock(spatial_dims, hid_chs[-1], hid_chs[-1], kernel_sizes[-1], 1, norm_name, act_name, dropout, time_emb_dim))
+
+        out_blocks = []
+        for i in range(1, self.depth):
+            for k in range(num_res_blocks + 1):
+                oc = hid_chs[i - 1 if k == 0 else i]
+                seq = [ConvBlock(spatial_dims, hid_chs[i] + oc, oc, kernel_sizes[i], 1, norm_name, act_name, dropout, time_emb_dim), att(oc, i)]
+                if i > 1 and k == 0:
+                    seq.append(BasicUp(spatial_dims, oc, oc, strides[i], strides[i], learnable_interpolation))
+                out_blocks.append(SequentialEmb(*seq))
+        self.out_blocks = nn.ModuleList(out_blocks)
+
+        out_ch_hor = out_ch * 2 if estimate_variance else out_ch
+        self.outc = zero_module(UnetOutBlock(spatial_dims, hid_chs[0], out_ch_hor, dropout=None))
+        if isinstance(deep_supervision, bool):
+            deep_supervision = self.depth - 2 if deep_supervision else 0
+        self.outc_ver = nn.ModuleList([
+            zero_module(UnetOutBlock(spatial_dims, hid_chs[i] + hid_chs[i - 1], out_ch, dropout=None)) for i in range(2, deep_supervision + 2)])
+
+        # all local embedders (Swish -> Linear(E, Cout)) batched into ONE GEMM per forward
+        self._emb_blocks = [m for m in self.modules() if isinstance(m, _EmbBlock) and hasattr(m, "local_embedder")]
+        self._emb_cache_key = None
+        self._emb_w = self._emb_b = None
+        self._emb_off = {}
+
+    # ------------------------------------------------------------------ embeddings
+    def _packed_local_embedders(self):
+        lins = [m.local_embedder[1] for m in self._emb_blocks]
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias._version) for l in lins)
+        if key != self._emb_cache_key:
+            with torch.no_grad():
+                self._emb_w = torch.cat([l.weight for l in lins], dim=0).contiguous()  # load-time packing (plumbing)
+                self._emb_b = torch.cat([l.bias for l in lins], dim=0).contiguous()
+            off = 0
+            self._emb_off = {}
+            for m, l in zip(self._emb_blocks, lins):
+                self._emb_off[id(m)] = (off, l.weight.shape[0])
+                off += l.weight.shape[0]
+            self._emb_cache_key = key
+        return self._emb_w, self._emb_b
+
+    def embed(self, t, condition):
+        """Global embedding [B,E] and the lookup giving every module its embedding (unet2.py:229-241)."""
+        time_emb = None if t is None else self.time_embedder(t)
+        if condition is None or self.cond_embedder is None:
+            emb = time_emb
+        elif time_emb is None:
+            emb = self.cond_embedder(condition)
+        else:  # save_add(time_emb, cond_emb): the lookup accumulates into the time embedding
+            emb = K.embedding_add(self.cond_embedder.embedding.weight, condition, time_emb)
+        if emb is None or not self._emb_blocks:
+            return emb, (lambda m: emb if isinstance(m, Attention) else None)
+        w, b = self._packed_local_embedders()
+        local_all = K.linear(emb, w, b, act_in=True)  # [B, sum Cout]
+
+        def lookup(m):
+            if isinstance(m, Attention):
+                return emb
+            o = self._emb_off.get(id(m))
+            return None if o is None else local_all[:, o[0]:o[0] + o[1]]
+
+        return emb, lookup
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def features(self, x_t, t=None, condition=None, self_cond=None):
+        """Everything of unet2.py:222-264 up to (not including) the 1x1 out convolution: (h NHWC, y_ver)."""
+        if not x_t.is_cuda:
+            raise RuntimeError("medfusion_amd.UNet runs on a ROCm device only (no CPU fallback)")
+        x_t = x_t.contiguous()
+        _, lookup = self.embed(t, condition)
+        if self.use_self_conditioning:
+            # reference concatenates zeros if self_cond is None else x_t ITSELF (unet2.py:245)
+            a = K.nchw_to_nhwc(x_t)
+            b = torch.zeros_like(a) if self_cond is None else a
+            h0 = self.in_conv((a, b))
+        else:
+            h0 = self.in_conv(x_t, in_layout=L.LAYOUT_NCHW)
+        x = [h0]
+        for blk in self.in_blocks:
+            x.append(blk(x[-1], lookup) if isinstance(blk, SequentialEmb) else blk(x[-1]))
+        h = self.middle_block(x[-1], lookup)
+        y_ver = []
+        for i in range(len(self.out_blocks), 0, -1):
+            hs = (h, x.pop())  # torch.cat([h, skip], 1) fused into the consumers
+            depth, j = i // (self.num_res_blocks + 1), i % (self.num_res_blocks + 1) - 1
+            if len(self.outc_ver) >= depth > 0 and j == 0:
+                y_ver.append(self.outc_ver[depth - 1](hs))
+            h = self.out_blocks[i - 1](hs, lookup)
+        return h, y_ver[::-1]
+
+    @torch.no_grad()
+    def forward(self, x_t, t=None, condition=None, self_cond=None):
+        """x_t [B,C,H,W] NCHW on the GPU; t [B] (long or float); condition [B] long | None.
+        Returns (y NCHW, y_ver list) like unet2.py:222-269."""
+        h, y_ver = self.features(x_t, t, condition, self_cond)
+        return self.outc(h), y_ver
+
+    @torch.no_grad()
+    def forward_split(self, x_t, t=None, condition=None, self_cond=None):
+        """estimate_variance=True: (pred, pred_var) == y.chunk(2, dim=1) of diffusion_pipeline.py:252 as two
+        contiguous tensors (the two halves of `outc` run as two 1x1 convolutions over the same features)."""
+        assert self.estimate_variance
+        h, _ = self.features(x_t, t, condition, self_cond)
+        c = self.out_ch
+        return self.outc(h, rows=slice(0, c)), self.outc(h, rows=slice(c, 2 * c))

@@ -1,0 +1,47 @@
+"""Shared test helpers.  The oracle (oracle/) is the CHECKER here, never the thing under test on GPU runs."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from oracle import restate as R
+from oracle import synth as S
+
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def gold(name: str) -> dict:
+    with np.load(GOLD / f"{name}.npz") as z:
+        return {k: z[k] for k in z.files}
+
+
+def T(a) -> torch.Tensor:
+    return torch.from_numpy(np.asarray(a))
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max-norm relative error: max|a-b| / max|b| (the metric of SURVEY §8d)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def to_product_kwargs(kw: dict) -> dict:
+    """oracle kwargs -> product kwargs (swap the embedder classes)."""
+    import medfusion_amd as M
+
+    kw = dict(kw)
+    if kw.get("time_embedder") is R.TimeEmbbeding:
+        kw["time_embedder"] = M.TimeEmbbeding
+    if kw.get("cond_embedder") is R.LabelEmbedder:
+        kw["cond_embedder"] = M.LabelEmbedder
+    return kw
+
+
+def oracle_noise(seed: int):
+    """HostNoise that replays the oracle's numpy-Philox draws (same draws the golden fixtures were made with)."""
+    import medfusion_amd as M
+
+    src = S.PhiloxNoise(seed)
+    return M.HostNoise(lambda shape: src(torch.empty(tuple(shape))))
