@@ -87,8 +87,10 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
 int mf_linear_f32(const float* x, int64_t x_stride, const float* w, const float* bias, float* y, int64_t y_stride,
                   int B, int In, int Out, int act_in, int act_out, int accumulate, void* stream);
 /* SinusoidalPosEmb (time_embedder.py:15-28): out[b][0:half] = sin(t f_k), [half:2half] = cos(t f_k),
- * f_k = exp(-(ln(max_period)/(half - shift)) k); flip swaps halves; odd dim zero-padded. */
-int mf_sinusoidal_f32(const float* t, float* out, int B, int dim, float max_period, float shift, int flip, void* stream);
+ * f_k = exp(-(ln(max_period)/(half - shift)) k); flip swaps halves; odd dim zero-padded.
+ * freqs: optional device table f_k[half] precomputed by the host exactly like the reference (a 1-ulp difference
+ * in f_k is amplified by t ~ 1000); NULL = compute with device expf. */
+int mf_sinusoidal_f32(const float* t, const float* freqs, float* out, int B, int dim, float max_period, float shift, int flip, void* stream);
 /* LabelEmbedder lookup + save_add (cond_embedders.py:19-24, conv_blocks.py:16-18): io[b][:] += table[idx[b]][:] */
 int mf_embedding_add_f32(const float* table, const int64_t* idx, float* io, int B, int D, int num_rows, void* stream);
 

@@ -9,6 +9,7 @@ namespace {
 // Every product/sum is rounded on its own (__fmul_rn/__fadd_rn block FMA contraction) so that, given
 // identical inputs, the result is bit-identical to ATen's chain of elementwise ops on CPU.
 __global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
+#pragma clang fp contract(off)  // on AMD __fmul_rn/__fadd_rn are plain operators: without this hipcc fuses them into FMAs
   const int step = a.step_dev ? *a.step_dev : a.step;
   const MfSchedStep S = a.table[step];
   const float* npost = a.noise_post ? a.noise_post + (long)step * a.noise_step_stride : nullptr;

@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   }
 }
 
-__global__ void sinusoidal_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim, float coef, int flip) {
+__global__ void sinusoidal_kernel(const float* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int B, int dim, float coef,
+                                  int flip) {
+#pragma clang fp contract(off)
   const int half = dim >> 1;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * dim) return;
@@ -77,7 +79,9 @@ __global__ void sinusoidal_kernel(const float* __restrict__ t, float* __restrict
     if (flip) jj = j < half ? j + half : j - half;
     const int k = jj < half ? jj : jj - half;
     // reference: exp(-emb * arange(half)) in fp32, then t * freq, then sin | cos (time_embedder.py:18-21)
-    const float freq = expf(-coef * (float)k);
+    // a 1-ulp difference in freq is amplified by t (up to 999): the host passes the table it computed exactly
+    // like the reference (torch.exp on CPU); device expf is the fallback
+    const float freq = freqs ? freqs[k] : expf(-coef * (float)k);
     const float a = t[b] * freq;
     v = jj < half ? sinf(a) : cosf(a);
   }
@@ -117,6 +121,7 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
 }
 
 __global__ void diag_gaussian_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ z, int N, int C, int HW) {
+#pragma clang fp contract(off)
   const long total = (long)N * C * HW;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -178,7 +183,7 @@ int mf_linear_f32(const float* x, int64_t x_stride, const float* w, const float*
   return check_launch("linear");
 }
 
-int mf_sinusoidal_f32(const float* t, float* out, int B, int dim, float max_period, float shift, int flip, void* stream) {
+int mf_sinusoidal_f32(const float* t, const float* freqs, float* out, int B, int dim, float max_period, float shift, int flip, void* stream) {
   MF_REQUIRE(t && out && B > 0 && dim > 1, MF_EINVAL, "sinusoidal: bad args");
   const int half = dim / 2;
   MF_REQUIRE((float)half - shift > 0.f, MF_EINVAL, "sinusoidal: half_dim - shift must be > 0");
@@ -186,7 +191,7 @@ int mf_sinusoidal_f32(const float* t, float* out, int B, int dim, float max_peri
   const float coef = (float)(log((double)max_period) / ((double)half - (double)shift));
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * B * dim);
-  hipLaunchKernelGGL(sinusoidal_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, t, out, B, dim, coef, flip);
+  hipLaunchKernelGGL(sinusoidal_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, t, freqs, out, B, dim, coef, flip);
   return check_launch("sinusoidal");
 }
 

@@ -124,11 +124,13 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_i
     return out
 
 
-def sinusoidal(t: torch.Tensor, dim: int, max_period: float = 10000.0, shift: float = 1.0, flip: bool = False) -> torch.Tensor:
-    _gpu(t)
+def sinusoidal(t: torch.Tensor, dim: int, max_period: float = 10000.0, shift: float = 1.0, flip: bool = False,
+               freqs: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _gpu(t, freqs)
     t = t.to(torch.float32).contiguous()
     out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
-    L.check(L.load().mf_sinusoidal_f32(t.data_ptr(), out.data_ptr(), t.shape[0], dim, max_period, shift, int(flip), stream()), "mf_sinusoidal_f32")
+    L.check(L.load().mf_sinusoidal_f32(t.data_ptr(), _ptr(freqs), out.data_ptr(), t.shape[0], dim, max_period, shift, int(flip), stream()),
+            "mf_sinusoidal_f32")
     return out
 
 

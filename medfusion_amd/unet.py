@@ -4,6 +4,7 @@ Same constructor arguments, `forward(x_t, t, condition, self_cond) -> (y, y_ver)
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 import torch
@@ -20,9 +21,20 @@ class SinusoidalPosEmb(nn.Module):
     def __init__(self, emb_dim=16, downscale_freq_shift=1, max_period=10000, flip_sin_to_cos=False):
         super().__init__()
         self.emb_dim, self.downscale_freq_shift, self.max_period, self.flip_sin_to_cos = emb_dim, downscale_freq_shift, max_period, flip_sin_to_cos
+        self._freqs = None
+
+    def freqs(self, device):
+        """exp(-ln(max_period)/(half - shift) * arange(half)) evaluated on the host with the reference's own ops
+        (time_embedder.py:17-18), uploaded once: a 1-ulp difference here is amplified ~1000x by t."""
+        if self._freqs is None or self._freqs.device != device:
+            half = self.emb_dim // 2
+            e = math.log(self.max_period) / (half - self.downscale_freq_shift)
+            self._freqs = torch.exp(-e * torch.arange(half)).to(device)
+        return self._freqs
 
     def forward(self, x):
-        return K.sinusoidal(x, self.emb_dim, float(self.max_period), float(self.downscale_freq_shift), self.flip_sin_to_cos)
+        return K.sinusoidal(x, self.emb_dim, float(self.max_period), float(self.downscale_freq_shift), self.flip_sin_to_cos,
+                            freqs=self.freqs(x.device))
 
 
 class TimeEmbbeding(nn.Module):

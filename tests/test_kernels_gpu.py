@@ -1,0 +1,302 @@
+"""Per-kernel parity on a real MI355X: each C-ABI entry point against a plain torch fp32 CPU reference of the same op
+(floating-point kernels) or the oracle's bit-level spec (scheduler step, Philox)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restate as R
+from oracle import synth as S
+from tests.util import relerr
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import medfusion_amd  # noqa: F401  (loads libmedfusion_hip.so; raises if missing)
+    return torch.device("cuda:0")
+
+
+def _rand(name, shape, scale=1.0):
+    return S.synth_input(name, shape, scale)
+
+
+def _conv_ref(x, x2, w, b, stride, pad, ups):
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest-exact")
+    return F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad).float()
+
+
+CONV_CASES = [
+    # (N, H, W, C1, C2, Cout, k, stride, ups)
+    (2, 8, 8, 32, 0, 64, 3, 1, 0),
+    (2, 8, 8, 64, 32, 32, 3, 1, 0),     # two-source (skip concat)
+    (3, 10, 12, 32, 0, 32, 3, 2, 0),    # BasicDown stride 2, ragged M
+    (2, 5, 6, 32, 0, 32, 3, 1, 1),      # BasicUp fused nearest x2
+    (2, 8, 8, 64, 0, 128, 1, 1, 0),     # 1x1 conv_res
+    (1, 16, 16, 256, 0, 256, 3, 1, 0),  # published 32^2-level shape (smaller HW)
+    (2, 8, 8, 512, 512, 512, 3, 1, 0),  # out-block two-source, long K -> split-K
+    (1, 7, 9, 96, 0, 96, 3, 1, 0),      # Cout = 96 (BN=32 path), ragged
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+def test_conv_igemm(dev, case, tile):
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32}.get(tile, 32)
+    if tile and co % bn:
+        pytest.skip("tile does not divide Cout")
+    x = _rand(f"cx{case}", (n, c1, h, w))
+    x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"cb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want = _conv_ref(x, x2, wt, b, stride, pad, ups)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wp = K.pack_conv_weight(wt.to(dev))
+    for sk in ([0] if tile == 0 else [0, 1, 2, 3]):
+        d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk)
+        y = K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d, x2=x2d))
+        assert y.shape == want.shape
+        assert relerr(y, want) < 1e-5, (case, tile, sk)  # fp32 fma chain vs fp64 reference, K up to 9216
+
+
+@pytest.mark.parametrize("case", [
+    (2, 8, 8, 8, 32, 3, 1, "nchw", "nhwc"),    # in_conv: NCHW latent in
+    (2, 8, 8, 32, 8, 1, 1, "nhwc", "nchw"),    # outc: NCHW out
+    (2, 9, 7, 3, 16, 3, 1, "nchw", "nhwc"),    # VAE inc (Cin=3)
+    (2, 8, 8, 64, 3, 1, 1, "nhwc", "nchw"),    # VAE outc
+    (2, 8, 8, 64, 16, 3, 1, "nhwc", "nhwc"),   # out_enc
+    (2, 8, 8, 8, 32, 1, 1, "nchw", "nhwc"),    # inc_dec conv_res
+    (2, 8, 8, 16, 16, 1, 1, "nhwc", "nchw"),
+    (2, 10, 12, 8, 16, 3, 2, "nhwc", "nhwc"),
+])
+def test_conv_direct(dev, case):
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    n, h, w, ci, co, k, stride, lin, lout = case
+    x = _rand(f"dx{case}", (n, ci, h, w))
+    wt = _rand(f"dw{case}", (co, ci, k, k), 1.0 / np.sqrt(ci * k * k))
+    b = _rand(f"db{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want = _conv_ref(x, None, wt, b, stride, pad, 0)
+    xd = x.to(dev) if lin == "nchw" else K.nchw_to_nhwc(x.to(dev))
+    d = K.make_conv_desc(n, h, w, ci, 0, co, k, stride, pad, 0, L.LAYOUT_NCHW if lin == "nchw" else L.LAYOUT_NHWC,
+                         L.LAYOUT_NCHW if lout == "nchw" else L.LAYOUT_NHWC)
+    y = K.conv2d(xd, K.pack_conv_weight(wt.to(dev)), b.to(dev), d)
+    if lout == "nhwc":
+        y = K.nhwc_to_nchw(y)
+    assert relerr(y, want) < 2e-6
+
+
+def test_conv_direct_two_source(dev):
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    x, x2 = _rand("d2x", (2, 8, 6, 6)), _rand("d2y", (2, 8, 6, 6))
+    wt, b = _rand("d2w", (4, 16, 1, 1), 0.25), _rand("d2b", (4,), 0.1)
+    want = _conv_ref(x, x2, wt, b, 1, 0, 0)
+    d = K.make_conv_desc(2, 6, 6, 8, 8, 4, 1, 1, 0, 0, L.LAYOUT_NHWC, L.LAYOUT_NCHW)
+    y = K.conv2d(K.nchw_to_nhwc(x.to(dev)), K.pack_conv_weight(wt.to(dev)), b.to(dev), d, x2=K.nchw_to_nhwc(x2.to(dev)))
+    assert relerr(y, want) < 2e-6
+
+
+def test_conv_rejects_bad_descriptor(dev):
+    from medfusion_amd import kernels as K
+    x = torch.zeros((1, 4, 4, 32), device=dev)
+    w = torch.zeros((32, 5, 5, 32), device=dev)
+    d = K.make_conv_desc(1, 4, 4, 32, 0, 32, 5, 1, 2)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        K.conv2d(x, w, None, d)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 32, 32), (2, 8, 8, 64, 8), (3, 5, 7, 256, 32), (1, 64, 64, 64, 8), (2, 4, 4, 1024, 32), (1, 3, 3, 96, 8)])
+def test_groupnorm_swish_residual_emb(dev, case):
+    from medfusion_amd import kernels as K
+    n, h, w, c, g = case
+    x = _rand(f"gx{case}", (n, c, h, w), 2.0) + 0.7
+    res = _rand(f"gr{case}", (n, c, h, w))
+    emb = _rand(f"ge{case}", (n, c + 8))[:, 4:4 + c]
+    gamma, beta = 1 + 0.2 * _rand(f"gg{case}", (c,)), _rand(f"gb{case}", (c,), 0.1)
+    gn = F.group_norm(x.double(), g, gamma.double(), beta.double(), 1e-5)
+    want = (gn * torch.sigmoid(gn) + res.double() + emb.double()[:, :, None, None]).float()
+    xd = K.nchw_to_nhwc(x.to(dev))
+    stats = K.gn_stats(xd, g)
+    mean = x.double().reshape(n, g, -1).mean(-1)
+    var = x.double().reshape(n, g, -1).var(-1, unbiased=False)
+    assert relerr(stats[..., 0], mean.float()) < 1e-5
+    assert relerr(stats[..., 1], (1 / torch.sqrt(var + 1e-5)).float()) < 1e-5
+    embd = torch.zeros((n, c + 8), device=dev)
+    embd[:, 4:4 + c] = emb.to(dev)
+    e = embd[:, 4:4 + c]
+    y = K.gn_apply(xd, stats, gamma.to(dev), beta.to(dev), g, 1, K.nchw_to_nhwc(res.to(dev)), e, e.stride(0))
+    assert relerr(K.nhwc_to_nchw(y), want) < 3e-6
+    # no-affine / no-act / in-place variants
+    y2 = K.gn_apply(xd, stats, None, None, g, 0)
+    assert relerr(K.nhwc_to_nchw(y2), F.group_norm(x.double(), g, None, None, 1e-5).float()) < 3e-6
+
+
+def test_groupnorm_large_group_fp64_combine(dev):
+    """VAE 256^2 level: 524 288 elements per group with a large mean -- fp32 E[x^2]-E[x]^2 would fail this."""
+    from medfusion_amd import kernels as K
+    x = torch.randn((1, 256, 256, 64), generator=torch.Generator().manual_seed(1)) * 0.5 + 30.0
+    stats = K.gn_stats(x.to(dev), 8)
+    xr = x.double().reshape(1, 256 * 256, 8, 8).permute(0, 2, 1, 3).reshape(1, 8, -1)
+    assert relerr(stats[..., 0], xr.mean(-1).float()) < 1e-6
+    assert relerr(stats[..., 1], (1 / torch.sqrt(xr.var(-1, unbiased=False) + 1e-5)).float()) < 2e-4
+
+
+@pytest.mark.parametrize("case", [(4, 256, 1024, False, True), (16, 1024, 1024, False, False), (3, 64, 10240, True, False), (20, 48, 30, True, False), (1, 20, 7, False, False)])
+def test_linear(dev, case):
+    from medfusion_amd import kernels as K
+    b, i, o, act_in, act_out = case
+    x, w, bias = _rand(f"lx{case}", (b, i)), _rand(f"lw{case}", (o, i), 1 / np.sqrt(i)), _rand(f"lb{case}", (o,), 0.1)
+    xin = x.double() * torch.sigmoid(x.double()) if act_in else x.double()
+    want = xin @ w.double().T + bias.double()
+    if act_out:
+        want = want * torch.sigmoid(want)
+    y = K.linear(x.to(dev), w.to(dev), bias.to(dev), act_in=act_in, act_out=act_out)
+    assert relerr(y, want.float()) < 2e-6
+
+
+def test_sinusoidal_and_embedding(dev):
+    from medfusion_amd import kernels as K
+    t = torch.tensor([0.0, 1.0, 37.0, 500.0, 999.0, 0.731])
+    for dim, mp, flip in ((256, 10000, False), (20, 10, False), (16, 10000, True), (17, 10000, False)):
+        want = R.SinusoidalPosEmb(dim, 1, mp, flip)(t)
+        half = dim // 2
+        freqs = torch.exp(-(np.log(mp) / (half - 1)) * torch.arange(half)).to(dev)  # host table, as the product passes it
+        got = K.sinusoidal(t.to(dev), dim, float(mp), 1.0, flip, freqs=freqs)
+        assert float((got.cpu() - want).abs().max()) < 5e-7, dim
+        got = K.sinusoidal(t.to(dev), dim, float(mp), 1.0, flip)  # device expf fallback: 1 ulp in f_k times t <= 999
+        assert float((got.cpu() - want).abs().max()) < 2e-4, dim
+    table = _rand("emb_table", (3, 64))
+    io = _rand("emb_io", (5, 64))
+    idx = torch.tensor([2, 0, 1, 1, 2])
+    got = K.embedding_add(table.to(dev), idx.to(dev), io.clone().to(dev))
+    assert torch.equal(got.cpu(), io + table[idx])
+
+
+def test_philox_normal_matches_spec(dev):
+    from medfusion_amd import kernels as K
+    out = torch.empty((6, 8, 16, 16), device=dev)
+    K.philox_normal(out, seed=(7 << 32) | 123, draw=5, sample_offset=10)
+    want = S.philox_normal((7 << 32) | 123, 5, np.arange(10, 16), 8 * 16 * 16).reshape(6, 8, 16, 16)
+    assert float((out.cpu() - torch.from_numpy(want)).abs().max()) < 2e-6
+    # shard invariance is exact: rows 12..15 alone
+    part = torch.empty((4, 8, 16, 16), device=dev)
+    K.philox_normal(part, seed=(7 << 32) | 123, draw=5, sample_offset=12)
+    assert torch.equal(part, out[2:])
+    # device-side step index
+    step = torch.tensor([3], dtype=torch.int32, device=dev)
+    ind = torch.empty_like(out)
+    K.philox_normal(ind, seed=(7 << 32) | 123, draw=2, sample_offset=10, step_dev=step, draw_stride=1)
+    assert torch.equal(ind, out)
+
+
+@pytest.mark.parametrize("objective,clip", [("x_T", False), ("x_T", True), ("x_0", True), ("x_0", False)])
+def test_sched_step_bit_exact(dev, objective, clip):
+    """The fused step must be BIT-identical to the oracle's chain of fp32 elementwise ops (same inputs)."""
+    import medfusion_amd as M
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    osch = R.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    psch = M.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    ts, _ = psch.loop_timesteps(7, True)
+    recs = psch.step_records(ts, True)
+    table = psch.upload_records(recs, dev)
+    rev = list(reversed(ts))
+    shape = (3, 8, 8, 8)
+    for i in (0, 3, 6):
+        t = torch.full((3,), rev[i], dtype=torch.long)
+        x_t, pc, pu = _rand(f"sx{i}", shape), _rand(f"sp{i}", shape), _rand(f"su{i}", shape)
+        npost, nddim = _rand(f"sn{i}", shape), _rand(f"sd{i}", shape)
+        g = 8.0
+        pred = pu + g * (pc - pu)
+        osch.noise_fn = lambda like: npost
+        if objective == "x_T":
+            prior, x0 = osch.estimate_x_t_prior_from_x_T(x_t, t, pred, clip_x0=clip)
+            xT = pred
+        else:
+            prior, x0 = osch.estimate_x_t_prior_from_x_0(x_t, t, pred, clip_x0=clip)
+            xT = osch.estimate_x_T(x_t, x_0=pred, t=t, clip_x0=clip)
+        want = prior
+        if i < 6:  # DDIM update, diffusion_pipeline.py:297-304
+            alpha, alpha_next = osch.alphas_cumprod[rev[i]], osch.alphas_cumprod[ts[7 - i - 2]]
+            sigma = 1 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            want = x0 * alpha_next.sqrt() + c * xT + sigma * nddim
+        d = [v.to(dev) for v in (x_t, pc, pu, npost, nddim)]
+        out, x0o, xTo = (torch.empty(shape, device=dev) for _ in range(3))
+        a = L.MfSchedArgs(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), None, d[3].data_ptr(), d[4].data_ptr(), 0, out.data_ptr(),
+                          x0o.data_ptr(), xTo.data_ptr(), table.data_ptr(), None, i, 0 if objective == "x_T" else 1, int(clip), g, out.numel())
+        K.sched_step(a)
+        assert torch.equal(x0o.cpu(), x0), (i, "x0")
+        assert torch.equal(xTo.cpu(), xT), (i, "xT")
+        assert torch.equal(out.cpu(), want), (i, "x_t")
+
+
+def test_sched_step_learned_variance(dev):
+    import medfusion_amd as M
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    osch = R.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    psch = M.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    for tval in (0, 5, 999):
+        recs = psch.step_records([tval], False)
+        table = psch.upload_records(recs, dev)
+        shape = (2, 8, 4, 4)
+        t = torch.full((2,), tval, dtype=torch.long)
+        x_t, pred, pv, npost = _rand("vx", shape), _rand("vp", shape), _rand("vv", shape, 0.5), _rand("vn", shape)
+        osch.noise_fn = lambda like: npost
+        prior, x0 = osch.estimate_x_t_prior_from_x_T(x_t, t, pred, clip_x0=False, var_scale=pv / 2 + 0.5)
+        d = [v.to(dev) for v in (x_t, pred, pv, npost)]
+        out, x0o = torch.empty(shape, device=dev), torch.empty(shape, device=dev)
+        a = L.MfSchedArgs(d[0].data_ptr(), d[1].data_ptr(), None, d[2].data_ptr(), d[3].data_ptr(), None, 0, out.data_ptr(), x0o.data_ptr(), None,
+                          table.data_ptr(), None, 0, 0, 0, 1.0, out.numel())
+        K.sched_step(a)
+        assert torch.equal(x0o.cpu(), x0)
+        assert relerr(out, prior) < 1e-6  # expf on device vs CPU
+
+
+@pytest.mark.parametrize("case", [(2, 4, 64, 64, 8), (2, 8, 100, 100, 32), (1, 3, 256, 256, 32), (2, 8, 64, 1, 4), (1, 8, 70, 130, 128)])
+def test_attention(dev, case):
+    from medfusion_amd import kernels as K
+    b, h, nq, nk, d = case
+    c = h * d
+    q, k, v = _rand(f"aq{case}", (b, c, nq)), _rand(f"ak{case}", (b, c, nk)), _rand(f"av{case}", (b, c, nk))
+    want = R.compute_attention(q.double(), k.double(), v.double(), h, d ** -0.25).float()  # [B, C, Nq]
+    tok = lambda z: z.transpose(1, 2).contiguous().to(dev)
+    got = K.attention(tok(q), tok(k), tok(v), h, d ** -0.25)
+    assert relerr(got.transpose(1, 2), want) < 5e-6
+
+
+def test_layernorm_geglu_add_layout(dev):
+    from medfusion_amd import kernels as K
+    x = _rand("ln_x", (3, 5, 7, 96), 2.0)
+    gmm, bta = 1 + 0.2 * _rand("ln_g", (96,)), _rand("ln_b", (96,), 0.1)
+    want = F.layer_norm(x.double(), (96,), gmm.double(), bta.double(), 1e-5).float()
+    assert relerr(K.layernorm(x.to(dev), gmm.to(dev), bta.to(dev)), want) < 3e-6
+    h = _rand("geglu", (2, 4, 4, 64), 2.0)
+    a, gate = h.double().chunk(2, dim=-1)
+    assert relerr(K.geglu(h.to(dev)), (a * F.gelu(gate)).float()) < 3e-6
+    y = _rand("lay", (2, 5, 6, 7))
+    yd = y.to(dev)
+    assert torch.equal(K.nhwc_to_nchw(K.nchw_to_nhwc(yd)), yd)
+    assert torch.equal(K.nchw_to_nhwc(yd).cpu(), y.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(K.add(yd, yd).cpu(), y + y)
+
+
+def test_no_cpu_fallback():
+    import medfusion_amd as M
+    from medfusion_amd import kernels as K
+    with pytest.raises(RuntimeError, match="no CPU"):
+        K.gn_stats(torch.zeros((1, 2, 2, 32)), 8)
+    u = M.UNet(**dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[32, 32, 64, 128], time_embedder_kwargs={"emb_dim": 64}, deep_supervision=False))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        u(torch.zeros((1, 8, 8, 8)), torch.zeros((1,)))
