@@ -20,6 +20,7 @@ using namespace mf;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -37,6 +38,7 @@ struct ConvP {
   int tiles_m, tiles_n;
   long slab;
   int in_nchw, out_nchw;
+  unsigned bytes1, bytes2, bytesw;  // buffer-descriptor extents (igemm path: all < 4 GiB, checked on the host)
 };
 
 // bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
@@ -47,7 +49,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + within;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SCHED>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BK = 32, LDK = BK + 4;
@@ -89,11 +91,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       a_ix0[q] = ox * p.stride - p.pad;
     } else {
       a_n[q] = 0;
-      a_iy0[q] = -(1 << 28);
+      a_iy0[q] = -(1 << 28);  // rows past M: always "out of bounds" -> zeros (address clamps to pixel 0 of image 0)
       a_ix0[q] = 0;
     }
   }
-  const float* wbase = p.w + (long)(n0 + srow) * p.K + skoff;
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.bytesw, 0x00020000);
+  const unsigned wboff = (unsigned)((n0 + srow) * p.K + skoff) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -110,27 +113,36 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   f32x4 ra[PA], rb[PB];
 
 // (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
+// Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
+// supplies the zero padding (an out-of-range offset returns 0) -- no branch, no select on the data, one basic block.
 #define MF_GLOAD(KC)                                                                                         \
   {                                                                                                          \
     const int c0_ = cc * BK;                                                                                 \
     const bool first_ = c0_ < p.C1;                                                                          \
-    const float* src_ = first_ ? p.x1 : p.x2;                                                                \
     const int Cs_ = first_ ? p.C1 : p.C2;                                                                    \
     const int coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                   \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+        const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000);              \
     _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                         \
       const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;                                                      \
       const bool ok = (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;                    \
       const int sy = iy >> p.ups, sx = ix >> p.ups;                                                          \
-      const long off = ((long)(a_n[q] + sy) * p.Win + sx) * Cs_ + coff_;                                     \
-      ra[q] = ok ? *reinterpret_cast<const f32x4*>(src_ + off) : f32x4{0.f, 0.f, 0.f, 0.f};               \
+      const unsigned off = (unsigned)(((a_n[q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                      \
+      ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
     }                                                                                                        \
     _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                           \
-        rb[q] = *reinterpret_cast<const f32x4*>(wbase + (long)q * RPP * p.K + (long)(KC) * BK);              \
+        rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                             \
+            rsw, wboff + (unsigned)(q * RPP * p.K + (KC) * BK) * 4u, 0, 0));                                 \
   }
-#define MF_ADVANCE()                      \
-  if (++cc == p.cchunks) {                \
-    cc = 0;                               \
-    if (++kx == p.KW) { kx = 0; ++ky; }   \
+#define MF_ADVANCE()                          \
+  {                                           \
+    ++cc;                                     \
+    const int w1_ = (cc == p.cchunks) ? 1 : 0; \
+    cc = w1_ ? 0 : cc;                        \
+    kx += w1_;                                \
+    const int w2_ = (kx == p.KW) ? 1 : 0;     \
+    kx = w2_ ? 0 : kx;                        \
+    ky += w2_;                                \
   }
 #define MF_LDS_STORE(BUF)                                                                                    \
   {                                                                                                          \
@@ -144,38 +156,101 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   const float* Aw = As + (wm * TM * 32) * LDK + frag_off;
   const float* Bw = Bs + (wn * TN * 32) * LDK + frag_off;
 
+  // Pipeline (one barrier per K-chunk, at the TOP of the iteration):
+  //   iteration k:  barrier | fragment reads (first 8-k slice) | LDS-store chunk k+1 (registers, loaded during
+  //                 iteration k-1) -> buf^1 | MFMAs of chunk k from buf with, interleaved between them, the global
+  //                 loads of chunk k+2 -> registers and the fragment reads of the next slices.
+  // PMC evidence (profiles/r01_pmc_conv.md): without the interleave every wave of a workgroup enters its memory
+  // phase together and the matrix pipe idles 30 % of the time; the MFMA is 64 cycles long, i.e. 16 issue slots each.
+  // Hazards: buf^1 was last read in iteration k-1 (all waves are past this iteration's barrier); chunk k in buf was
+  // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
+  // The gather of chunk k+2 is cut into PA + PB + 1 "pieces" (piece 0: advance the (tap, channel-chunk) counters and
+  // build the source descriptor; then one buffer load each) and one piece is issued after each MFMA sub-group;
+  // sched_barrier(0) fences keep the compiler from regrouping them in front of / behind the MFMA stream.
+  // (PI is a compile-time constant once the slice loops are unrolled: the array indices fold to registers.)
+#define MF_PIECE(PI, KC)                                                                                             \
+  {                                                                                                                  \
+    const int pi_ = (PI);                                                                                            \
+    if (pi_ == 0) {                                                                                                  \
+      MF_ADVANCE();                                                                                                  \
+      const int c0_ = cc * BK;                                                                                       \
+      const bool first_ = c0_ < p.C1;                                                                                \
+      g_Cs = first_ ? p.C1 : p.C2;                                                                                   \
+      g_coff = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                  \
+      g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
+    } else if (pi_ <= PA) {                                                                                          \
+      const int q = pi_ - 1;                                                                                         \
+      const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;                                                              \
+      const bool ok = (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;                            \
+      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                                  \
+      const unsigned off = (unsigned)(((a_n[q] + sy) * p.Win + sx) * g_Cs + g_coff) * 4u;                            \
+      ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rs, ok ? off : 0xFFFFFFF0u, 0, 0));  \
+    } else if (pi_ <= PA + PB) {                                                                                     \
+      const int q = pi_ - 1 - PA;                                                                                    \
+      rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                                       \
+          rsw, wboff + (unsigned)(q * RPP * p.K + (KC) * BK) * 4u, 0, 0));                                           \
+    }                                                                                                                \
+  }
+  int g_Cs = 0, g_coff = 0;
+  __amdgpu_buffer_rsrc_t g_rs = rsw;
+  constexpr int NSEG = 16;                          // MFMA sub-groups per chunk: 4 slices x 4 k-pairs
+  constexpr int PIECES = PA + PB + 1;
+  constexpr int PSTRIDE = NSEG / PIECES > 0 ? NSEG / PIECES : 1;  // spread the pieces over the sub-groups
+  static_assert(PIECES <= NSEG, "more gather pieces than MFMA sub-groups");
+
+#define MF_COMPUTE(DO_STORE, DO_LOAD, KC)                                                                            \
+  {                                                                                                                  \
+    __syncthreads();                                                                                                 \
+    const float* Ab = Aw + buf * BM * LDK;                                                                           \
+    const float* Bb = Bw + buf * BN * LDK;                                                                           \
+    f32x4 fa[2][TM], fb[2][TN];                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
+    if (DO_STORE) MF_LDS_STORE(buf ^ 1);                                                                             \
+    if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                                    \
+    if ((DO_LOAD) && !SCHED) { MF_ADVANCE(); MF_GLOAD(KC); }                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
+      const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
+      if (kk + 1 < BK / 8) {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+            fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+            fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                          \
+      }                                                                                                              \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);      \
+        if ((DO_LOAD) && SCHED) {                                                                                    \
+          const int seg = kk * 4 + s;                                                                                \
+          if (seg % PSTRIDE == 0 && seg / PSTRIDE < PIECES) MF_PIECE(seg / PSTRIDE, KC);                             \
+          __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                            \
+      }                                                                                                              \
+    }                                                                                                                \
+    buf ^= 1;                                                                                                        \
+  }
+
   if (kc_beg < kc_end) {
     MF_GLOAD(kc_beg);
     MF_LDS_STORE(0);
+    if (kc_beg + 1 < kc_end) {
+      MF_ADVANCE();
+      MF_GLOAD(kc_beg + 1);
+    }
   }
-  __syncthreads();
 
   int buf = 0;
-  for (int kc = kc_beg; kc < kc_end; ++kc) {
-    const bool has_next = kc + 1 < kc_end;
-    if (has_next) {
-      MF_ADVANCE();
-      MF_GLOAD(kc + 1);
+  int kc = kc_beg;
+  for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
+    MF_COMPUTE(true, true, kc + 2);
+  }
+  for (; kc < kc_end; ++kc) {      // last two chunks: nothing left to load, then nothing left to store
+    if (kc + 1 < kc_end) {
+      MF_COMPUTE(true, false, 0);
+    } else {
+      MF_COMPUTE(false, false, 0);
     }
-    const float* Ab = Aw + buf * BM * LDK;
-    const float* Bb = Bw + buf * BN * LDK;
-#pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + kk * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + kk * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (has_next) MF_LDS_STORE(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 
   // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -273,6 +348,63 @@ __global__ void conv_direct_kernel(const ConvP p) {
     p.y[(long)m * p.Cout + co] = acc;
 }
 
+
+// Small-Cin convolution (UNet in_conv 8->256, VAE inc_dec 8->512, VAE inc 3->64): K = KH*KW*Cin <= 160.
+// A persistent block keeps a transposed weight tile W^T[k][co] (co <= 256) in LDS, then walks pixel groups:
+// the im2col patch of 16 pixels goes to LDS (broadcast reads), lane = output channel => coalesced NHWC stores.
+constexpr int kSmallPix = 16, kSmallCo = 256, kSmallMaxK = 160;
+
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int groups) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wT = sm;                                   // [K][kSmallCo]
+  float* patch = sm + (size_t)p.K * kSmallCo;       // [kSmallPix][K]
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * kSmallCo;
+  const int nco = min(kSmallCo, p.Cout - co0);
+  for (int i = tid; i < nco * p.K; i += 256) {      // coalesced read of [co][k], transposed write
+    const int co = i / p.K, k = i - co * p.K;
+    wT[k * kSmallCo + co] = p.w[(long)(co0 + co) * p.K + k];
+  }
+  const float bias = (p.bias && tid < nco) ? p.bias[co0 + tid] : 0.f;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int m0 = g * kSmallPix;
+    __syncthreads();
+    for (int i = tid; i < kSmallPix * p.K; i += 256) {
+      const int px = i / p.K, k = i - px * p.K;
+      const int tap = k / p.Cin, ci = k - tap * p.Cin;
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int m = m0 + px;
+      float v = 0.f;
+      if (m < p.M) {
+        const int n = m / p.HWout, rem = m - n * p.HWout;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+        if ((unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff) {
+          const int sy = iy >> p.ups, sx = ix >> p.ups;
+          v = p.in_nchw ? p.x1[((long)(n * p.C1 + ci) * p.Hin + sy) * p.Win + sx]
+                        : (ci < p.C1 ? p.x1[((long)(n * p.Hin + sy) * p.Win + sx) * p.C1 + ci]
+                                     : p.x2[((long)(n * p.Hin + sy) * p.Win + sx) * p.C2 + (ci - p.C1)]);
+        }
+      }
+      patch[i] = v;
+    }
+    __syncthreads();
+    if (tid < nco) {
+      float acc[kSmallPix];
+#pragma unroll
+      for (int q = 0; q < kSmallPix; ++q) acc[q] = bias;
+      for (int k = 0; k < p.K; ++k) {
+        const float wv = wT[k * kSmallCo + tid];
+#pragma unroll
+        for (int q = 0; q < kSmallPix; ++q) acc[q] = fmaf(patch[q * p.K + k], wv, acc[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < kSmallPix; ++q)
+        if (m0 + q < p.M) p.y[(long)(m0 + q) * p.Cout + co0 + tid] = acc[q];
+    }
+  }
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW) {
   const long total = (long)Cout * Cin * KH * KW;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -291,6 +423,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 struct TileCfg { int id, BM, BN, WM, WN; };
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2}, {2, 128, 64, 2, 2}, {3, 64, 128, 2, 2}, {4, 64, 64, 2, 2}, {5, 128, 32, 4, 1}, {6, 64, 32, 2, 1},
+    {7, 128, 128, 4, 2}, {8, 128, 128, 2, 4}, {9, 128, 256, 2, 4},
+    {13, 64, 128, 2, 2}, {17, 128, 128, 4, 2}, {18, 128, 128, 2, 4},  // same tiles WITH the pinned interleave (A/B only)
 };
 
 struct Plan {
@@ -336,19 +470,21 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     pl->cfg = *c;
   } else {
-    const int BN = d->Cout % 128 == 0 ? 128 : (d->Cout % 64 == 0 ? 64 : 32);
-    const long t128 = (long)cdiv(pl->M, 128) * (d->Cout / BN);
-    // prefer 128-row tiles; drop to 64 rows only when even split-K cannot fill the chip
-    const int BM = (pl->M >= 128 && (t128 >= 96 || nk >= 64)) ? 128 : 64;
-    for (const auto& k : kCfgs) if (k.BM == BM && k.BN == BN) pl->cfg = k;
+    // From scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.txt): the 8-wave 128x128 tile (2 waves per SIMD inside
+    // ONE workgroup: half the LDS/L2 traffic of two 64x128 workgroups) is best or within 2 % of best for every shape with
+    // Cout % 128 == 0; 64x64 for the 64-channel VAE level.  Split-K (below) tops the grid up to >= 512 workgroups.
+    int id = 6;
+    if (d->Cout % 128 == 0 && pl->M >= 128) id = 8;
+    else if (d->Cout % 64 == 0) id = 4;
+    for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
   const long tiles = (long)cdiv(pl->M, pl->cfg.BM) * (d->Cout / pl->cfg.BN);
   int sk = 1;
   if (d->splitk_hint > 0) {
     sk = d->splitk_hint;
   } else {
-    // aim for >= ~2 workgroups per CU (256 CUs), keep >= 16 chunks (512 k) per split
-    while (tiles * sk < 384 && nk / (sk * 2) >= 16 && sk < 16) sk *= 2;
+    // aim for >= 2 workgroups per CU (256 CUs), keep >= 4 chunks (128 k) per split
+    while (tiles * sk < 512 && nk / (sk * 2) >= 4 && sk < 16) sk *= 2;
   }
   if (sk > nk) sk = nk;
   pl->nk_per_split = cdiv(nk, sk);
@@ -356,17 +492,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool SCHED = false>
 int launch_igemm(const ConvP& p, hipStream_t s) {
   constexpr int LDK = 36;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -407,9 +543,24 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float*
   p.in_nchw = d->in_layout == MF_LAYOUT_NCHW; p.out_nchw = d->out_layout == MF_LAYOUT_NCHW;
   p.cchunks = p.Cin / 32; p.nk = d->KH * d->KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
   p.tiles_m = 0; p.tiles_n = 0; p.slab = (long)pl.M * d->Cout;
+  p.bytes1 = p.bytes2 = p.bytesw = 0;
   const double flops = 2.0 * pl.M * (double)d->Cout * pl.K;
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
 
+  if (!pl.igemm && !p.out_nchw && p.Cin <= 16 && pl.K <= kSmallMaxK && d->Cout % 64 == 0) {
+    ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
+    const int groups = cdiv(pl.M, kSmallPix);
+    const int cotiles = cdiv(d->Cout, kSmallCo);
+    const size_t lds = ((size_t)pl.K * kSmallCo + (size_t)kSmallPix * pl.K) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr = true;
+    }
+    int gx = groups < 1024 ? groups : 1024;
+    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
+    return check_launch("conv_smallcin");
+  }
   if (!pl.igemm) {
     ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
     const long total = (long)pl.M * d->Cout;
@@ -423,6 +574,12 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float*
 
   p.tiles_m = cdiv(pl.M, pl.cfg.BM);
   p.tiles_n = d->Cout / pl.cfg.BN;
+  {
+    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = 4.0 * d->Cout * pl.K;
+    MF_REQUIRE(b1 < 4294967040.0 && b2 < 4294967040.0 && bw < 4294967040.0, MF_EUNSUPPORTED,
+               "conv: a source tensor exceeds the 4 GiB buffer-descriptor range (shard the batch)");
+    p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;
+  }
   if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
     MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv: workspace %zu < %zu", workspace_bytes, need);
@@ -437,6 +594,12 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float*
       case 4: rc = launch_igemm<64, 64, 2, 2>(p, s); break;
       case 5: rc = launch_igemm<128, 32, 4, 1>(p, s); break;
       case 6: rc = launch_igemm<64, 32, 2, 1>(p, s); break;
+      case 7: rc = launch_igemm<128, 128, 4, 2>(p, s); break;
+      case 8: rc = launch_igemm<128, 128, 2, 4>(p, s); break;
+      case 9: rc = launch_igemm<128, 256, 2, 4>(p, s); break;
+      case 13: rc = launch_igemm<64, 128, 2, 2, true>(p, s); break;
+      case 17: rc = launch_igemm<128, 128, 4, 2, true>(p, s); break;
+      case 18: rc = launch_igemm<128, 128, 2, 4, true>(p, s); break;
       default: set_error("conv: no tile config"); rc = MF_EINVAL;
     }
   }

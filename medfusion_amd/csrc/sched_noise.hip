@@ -6,10 +6,11 @@ using namespace mf;
 
 namespace {
 
-// Every product/sum is rounded on its own (__fmul_rn/__fadd_rn block FMA contraction) so that, given
-// identical inputs, the result is bit-identical to ATen's chain of elementwise ops on CPU.
+// Every product/sum is rounded on its own so that, given identical inputs, the result is bit-identical to
+// ATen's chain of elementwise ops on CPU.  The library is built with -ffp-contract=off (on AMD the __f*_rn
+// intrinsics are plain operators and would otherwise be fused into FMAs); the pragma restates it locally.
 __global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
-#pragma clang fp contract(off)  // on AMD __fmul_rn/__fadd_rn are plain operators: without this hipcc fuses them into FMAs
+#pragma clang fp contract(off)
   const int step = a.step_dev ? *a.step_dev : a.step;
   const MfSchedStep S = a.table[step];
   const float* npost = a.noise_post ? a.noise_post + (long)step * a.noise_step_stride : nullptr;
@@ -20,29 +21,47 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
     float pred = a.pred[i];
     if (a.pred_uncond) {  // diffusion_pipeline.py:244  pred_uncond + g * (pred_cond - pred_uncond)
       const float pu = a.pred_uncond[i];
-      pred = __fadd_rn(pu, __fmul_rn(a.guidance_scale, __fsub_rn(pred, pu)));
+      const float dlt = pred - pu;
+      const float sc = a.guidance_scale * dlt;
+      pred = pu + sc;
     }
     float x0, xT;
     if (a.objective == 0) {  // 'x_T': gaussian_scheduler.py:119-124
-      x0 = __fsub_rn(__fmul_rn(S.sqrt_recip_ac, xt), __fmul_rn(S.sqrt_recipm1_ac, pred));
+      const float p1 = S.sqrt_recip_ac * xt;
+      const float p2 = S.sqrt_recipm1_ac * pred;
+      x0 = p1 - p2;
       if (a.clip_x0) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
       xT = pred;
     } else {  // 'x_0': diffusion_pipeline.py:264-267, gaussian_scheduler.py:127-131
       x0 = a.clip_x0 ? fminf(fmaxf(pred, -1.0f), 1.0f) : pred;
-      xT = __fdiv_rn(__fsub_rn(__fmul_rn(S.sqrt_recip_ac, xt), x0), S.sqrt_recipm1_ac);
+      const float p1 = S.sqrt_recip_ac * xt;
+      const float df = p1 - x0;
+      xT = df / S.sqrt_recipm1_ac;
     }
     // posterior mean / std: gaussian_scheduler.py:95-100
-    const float mean = __fadd_rn(__fmul_rn(S.coef1, x0), __fmul_rn(S.coef2, xt));
+    const float m1 = S.coef1 * x0;
+    const float m2 = S.coef2 * xt;
+    const float mean = m1 + m2;
     float sd = S.std_fixed;
     if (a.pred_var) {  // learned variance: var_scale = pred_var/2 + 0.5 (diffusion_pipeline.py:256), :110-116
-      const float vs = __fadd_rn(__fdiv_rn(a.pred_var[i], 2.0f), 0.5f);
-      const float lv = __fadd_rn(__fmul_rn(vs, S.log_var_max), __fmul_rn(__fsub_rn(1.0f, vs), S.log_var_min));
-      sd = S.t == 0 ? 0.0f : expf(__fmul_rn(0.5f, lv));
+      const float hv = a.pred_var[i] / 2.0f;
+      const float vs = hv + 0.5f;
+      const float l1 = vs * S.log_var_max;
+      const float om = 1.0f - vs;
+      const float l2 = om * S.log_var_min;
+      const float lv = l1 + l2;
+      const float hl = 0.5f * lv;
+      sd = S.t == 0 ? 0.0f : expf(hl);
     }
-    const float prior = __fadd_rn(mean, __fmul_rn(sd, npost ? npost[i] : 0.0f));
+    const float sn = sd * (npost ? npost[i] : 0.0f);
+    const float prior = mean + sn;
     float xn = prior;
     if (S.mode == 1) {  // DDIM: x_0*sqrt(a_next) + c*x_T + sigma*noise  (diffusion_pipeline.py:304)
-      xn = __fadd_rn(__fadd_rn(__fmul_rn(x0, S.ddim_sqrt_an), __fmul_rn(S.ddim_c, xT)), __fmul_rn(S.ddim_sigma, nddim ? nddim[i] : 0.0f));
+      const float d1 = x0 * S.ddim_sqrt_an;
+      const float d2 = S.ddim_c * xT;
+      const float d3 = S.ddim_sigma * (nddim ? nddim[i] : 0.0f);
+      const float d12 = d1 + d2;
+      xn = d12 + d3;
     }
     a.x_t_out[i] = xn;
     if (a.x0_out) a.x0_out[i] = x0;

@@ -130,8 +130,10 @@ __global__ void diag_gaussian_kernel(const float* __restrict__ mom, const float*
   const float mean = mom[n * 2 * per + r];
   float logvar = mom[n * 2 * per + per + r];
   logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
-  const float sd = expf(__fmul_rn(0.5f, logvar));
-  z[i] = __fadd_rn(mean, __fmul_rn(sd, noise[i]));
+  const float hl = 0.5f * logvar;
+  const float sd = expf(hl);
+  const float sn = sd * noise[i];
+  z[i] = mean + sn;
 }
 
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-shape timing of every convolution of the published UNet (B per GPU) and VAE decoder, over the implicit-GEMM
+tile configs and split-K factors (tuning tool for the planner in csrc/conv.hip; run on the GPU box)."""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+from medfusion_amd import kernels as K
+from medfusion_amd import lib as L
+
+
+def unet_shapes(B):
+    # (name, N, H, W, C1, C2, Cout, k, stride, ups, count per UNet call)
+    S = []
+    def res(name, h, c1, c2, co, n=1):
+        S.append((f"{name}.c0", B, h, h, c1, c2, co, 3, 1, 0, n))
+        S.append((f"{name}.c1", B, h, h, co, 0, co, 3, 1, 0, n))
+        if c1 + c2 != co:
+            S.append((f"{name}.res", B, h, h, c1, c2, co, 1, 1, 0, n))
+    res("in32 R256", 32, 256, 0, 256, 2)
+    S.append(("down32", B, 32, 32, 256, 0, 256, 3, 2, 0, 1))
+    res("in16 R256-512", 16, 256, 0, 512)
+    res("in16 R512", 16, 512, 0, 512)
+    S.append(("down16", B, 16, 16, 512, 0, 512, 3, 2, 0, 1))
+    res("in8 R512-1024", 8, 512, 0, 1024)
+    res("in8/mid R1024", 8, 1024, 0, 1024, 3)
+    res("out8 R2048-1024", 8, 1024, 1024, 1024, 2)
+    res("out8 R1536-512", 8, 1024, 512, 512)
+    S.append(("up8->16", B, 8, 8, 512, 0, 512, 3, 1, 1, 1))
+    res("out16 R1024-512", 16, 512, 512, 512, 2)
+    res("out16 R768-256", 16, 512, 256, 256)
+    S.append(("up16->32", B, 16, 16, 256, 0, 256, 3, 1, 1, 1))
+    res("out32 R512-256", 32, 256, 256, 256, 3)
+    return S
+
+
+def vae_shapes(B):
+    S = []
+    S.append(("vae R512@32.c1", B, 32, 32, 512, 0, 512, 3, 1, 0, 1))
+    for h, ci, co in ((32, 512, 256), (64, 256, 128), (128, 128, 64)):
+        S.append((f"vae up{h}", B, h, h, ci, 0, co, 3, 1, 1, 1))
+        S.append((f"vae R{co}@{2*h}", B, 2 * h, 2 * h, co, 0, co, 3, 1, 0, 2))
+    return S
+
+
+def time_conv(x1, x2, w, b, d, reps):
+    y = K.conv2d(x1, w, b, d, x2=x2)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        K.conv2d(x1, w, b, d, x2=x2, out=y)
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--vae-batch", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--quick", action="store_true", help="auto config only")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tot_auto = tot_best = tot_fl = 0.0
+    print(f"{'shape':24s} {'M':>7s} {'N':>5s} {'K':>6s} {'GF':>7s} | {'auto ms':>8s} {'TF':>6s} | best cfg (tile,splitk) ms TF | all")
+    for name, n, h, w_, c1, c2, co, k, st, ups, cnt in unet_shapes(args.batch) + vae_shapes(args.vae_batch):
+        pad = 1 if k == 3 else 0
+        x1 = torch.randn((n, h, w_, c1), generator=g).to(dev)
+        x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
+        wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
+        b = torch.randn((co,), generator=g).to(dev)
+        d0 = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups)
+        ho, wo = K.conv_out_hw(d0)
+        M, Kk = n * ho * wo, k * k * (c1 + c2)
+        gf = 2.0 * M * co * Kk / 1e9
+        time_conv(x1, x2, wt, b, d0, args.reps)  # clock/cache warm-up
+        t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
+        res = []
+        if not args.quick:
+            for tile in (1, 3, 4, 7, 8, 9, 13, 17, 18):
+                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 13: 128, 17: 128, 18: 128}[tile]
+                if co % bn:
+                    continue
+                for sk in (1, 2, 4, 8, 16):
+                    if sk > 1 and Kk // 32 // sk < 8:
+                        continue
+                    d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk)
+                    res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))
+            res.sort()
+        best = res[0] if res else (t_auto, 0, 0)
+        tot_auto += t_auto * cnt
+        tot_best += best[0] * cnt
+        tot_fl += gf * cnt
+        allres = " ".join(f"{t}/{s}:{ms:.3f}" for ms, t, s in res[:8])
+        print(f"{name:24s} {M:7d} {co:5d} {Kk:6d} {gf:7.2f} | {t_auto:8.3f} {gf / t_auto:6.1f} | ({best[1]},{best[2]}) {best[0]:.3f} {gf / best[0]:6.1f} | {allres}", flush=True)
+    print(f"TOTAL weighted: auto {tot_auto:.2f} ms ({tot_fl / tot_auto:.1f} TF)  best {tot_best:.2f} ms ({tot_fl / tot_best:.1f} TF)  flops {tot_fl:.1f} GF")
+
+
+if __name__ == "__main__":
+    main()

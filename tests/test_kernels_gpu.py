@@ -44,11 +44,11 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv_igemm(dev, case, tile):
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, stride, ups = case
-    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32}.get(tile, 32)
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32, 7: 128, 8: 128, 9: 256}.get(tile, 32)
     if tile and co % bn:
         pytest.skip("tile does not divide Cout")
     x = _rand(f"cx{case}", (n, c1, h, w))
@@ -76,6 +76,12 @@ def test_conv_igemm(dev, case, tile):
     (2, 8, 8, 8, 32, 1, 1, "nchw", "nhwc"),    # inc_dec conv_res
     (2, 8, 8, 16, 16, 1, 1, "nhwc", "nchw"),
     (2, 10, 12, 8, 16, 3, 2, "nhwc", "nhwc"),
+    (2, 8, 8, 8, 64, 3, 1, "nchw", "nhwc"),     # small-Cin kernel (UNet in_conv shape family)
+    (3, 9, 7, 8, 256, 3, 1, "nchw", "nhwc"),
+    (1, 8, 8, 8, 512, 3, 1, "nchw", "nhwc"),    # VAE inc_dec 8->512 (two co tiles)
+    (1, 8, 8, 8, 512, 1, 1, "nchw", "nhwc"),    # its 1x1 conv_res
+    (2, 9, 7, 3, 64, 3, 1, "nchw", "nhwc"),     # VAE inc 3->64
+    (2, 6, 6, 16, 128, 3, 2, "nhwc", "nhwc"),
 ])
 def test_conv_direct(dev, case):
     from medfusion_amd import kernels as K
@@ -104,6 +110,17 @@ def test_conv_direct_two_source(dev):
     d = K.make_conv_desc(2, 6, 6, 8, 8, 4, 1, 1, 0, 0, L.LAYOUT_NHWC, L.LAYOUT_NCHW)
     y = K.conv2d(K.nchw_to_nhwc(x.to(dev)), K.pack_conv_weight(wt.to(dev)), b.to(dev), d, x2=K.nchw_to_nhwc(x2.to(dev)))
     assert relerr(y, want) < 2e-6
+
+
+def test_conv_smallcin_two_source(dev):
+    """in_conv with self-conditioning: torch.cat([x_t, self_cond]) as two NHWC sources of 8 channels each."""
+    from medfusion_amd import kernels as K
+    x, x2 = _rand("s2x", (2, 8, 6, 6)), _rand("s2y", (2, 8, 6, 6))
+    wt, b = _rand("s2w", (64, 16, 3, 3), 1 / 12.0), _rand("s2b", (64,), 0.1)
+    want = _conv_ref(x, x2, wt, b, 1, 1, 0)
+    d = K.make_conv_desc(2, 6, 6, 8, 8, 64, 3, 1, 1)
+    y = K.conv2d(K.nchw_to_nhwc(x.to(dev)), K.pack_conv_weight(wt.to(dev)), b.to(dev), d, x2=K.nchw_to_nhwc(x2.to(dev)))
+    assert relerr(K.nhwc_to_nchw(y), want) < 2e-6
 
 
 def test_conv_rejects_bad_descriptor(dev):
