@@ -65,6 +65,13 @@ size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,
                   void* workspace, size_t workspace_bytes, const MfConvDesc* d, void* stream);
 
+/* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
+ * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
+ * parts = mf_conv2d_gn_parts(d, G); 0 means this convolution cannot emit them (use mf_gn_stats_partial_f32). */
+int mf_conv2d_gn_parts(const MfConvDesc* d, int G);
+int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y, void* workspace,
+                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream);
+
 /* ------------------------------------------------------------------ GroupNorm + Swish + residual + embedding
  * Replaces nn.GroupNorm + MONAI Swish + `out + residual` + `x += emb` at conv_blocks.py:186-191,
  * :236-240, :360-363 (UnetResBlock) / :298-301 (UnetBasicBlock).  NHWC.
@@ -73,6 +80,15 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
 size_t mf_gn_stats_workspace_bytes(int N, int HW, int C, int G);
 int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t workspace_bytes, int N, int HW, int C, int G,
                     float eps, void* stream);
+/* Two-kernel form used on the hot path: partial sums [N][parts][G][2] (doubles; parts = mf_gn_partial_parts(HW), or emitted
+ * by mf_conv2d_gn_f32), then ONE pass that finalises mean/rstd per workgroup and applies norm+affine+act+residual+emb. */
+int mf_gn_partial_parts(int HW);
+int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int C, int G, void* stream);
+/* partial sums -> stats[n][g] = {mean, rstd} (tiny kernel; measured cheaper than finalising inside every apply workgroup) */
+int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream);
+int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, float eps, const float* gamma, const float* beta,
+                            const float* residual, const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G,
+                            int act, void* stream);
 /* out = act(gn(x) * gamma + beta) + residual + emb[n*emb_stride + c]; act: 0 none, 1 Swish x*sigmoid(x).
  * gamma/beta NULL => no affine; stats NULL => no normalisation; residual / emb NULL => skipped.
  * out may alias x. */

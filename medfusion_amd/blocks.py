@@ -69,7 +69,8 @@ class Conv(nn.Module):
         self._packed = _Packed()
         self._descs = {}
 
-    def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None) -> torch.Tensor:
+    def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0):
+        """gn_groups > 0: also return the partial statistics of the GroupNorm that follows -> (y, partial, parts)."""
         x1, x2 = _split(x)
         if in_layout == L.LAYOUT_NCHW:
             n, c1, h, w = x1.shape
@@ -78,17 +79,26 @@ class Conv(nn.Module):
         c2 = 0 if x2 is None else x2.shape[-1]
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
-        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None)
-        d = self._descs.get(key)
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups)
+        ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
-        if d is None:
+        if ent is None:
             d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout)
-            self._descs[key] = d
+            ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
+            self._descs[key] = ent
+        d, parts = ent
         wp = self._packed.get(self.weight)
         b = self.bias
         if rows is not None:  # output-channel slice (learned-variance head split)
             wp, b = wp[rows], b[rows]
-        return K.conv2d(x1, wp, b, d, x2=x2, out=out)
+        if not gn_groups:
+            return K.conv2d(x1, wp, b, d, x2=x2, out=out)
+        if parts > 0:    # statistics fused into the conv epilogue / split-K reducer
+            y, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2)
+            return y, partial, parts
+        y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
+        partial, parts = K.gn_stats_partial(y, gn_groups)
+        return y, partial, parts
 
 
 class GroupNorm(nn.Module):
@@ -125,15 +135,20 @@ class BasicBlock(nn.Module):
         self.has_act = act_name is not None
 
     def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC):
-        y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         has_norm = hasattr(self, "norm")
-        if not (has_norm or self.has_act or residual is not None or emb is not None):
+        if has_norm:
+            if out_layout != L.LAYOUT_NHWC:
+                raise RuntimeError("norm/act epilogue needs NHWC")
+            nm = self.norm
+            y, partial, parts = self.conv(x, in_layout=in_layout, gn_groups=nm.num_groups)
+            n, h, w, c = y.shape
+            stats = K.gn_finalize(partial, parts, h * w, c, nm.num_groups, nm.eps)
+            return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+        y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
+        if not (self.has_act or residual is not None or emb is not None):
             return y
         if out_layout != L.LAYOUT_NHWC:
-            raise RuntimeError("norm/act epilogue needs NHWC")
-        if has_norm:
-            stats = K.gn_stats(y, self.norm.num_groups, self.norm.eps)
-            return K.gn_apply(y, stats, self.norm.weight, self.norm.bias, self.norm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+            raise RuntimeError("act/residual epilogue needs NHWC")
         return K.gn_apply(y, None, None, None, 1, int(self.has_act), residual, emb, emb_stride, out=y)
 
 

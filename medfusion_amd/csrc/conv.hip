@@ -15,6 +15,7 @@
 //  * split-K (deterministic slabs + reduce kernel) fills the chip when M*Cout is small (8x8, 16x16 levels).
 //  * conv_direct_kernel: any shape / NCHW edges (Cin = 8|3, Cout = 8|3|16): <0.2 % of the FLOPs.
 #include "common.h"
+#include "gn_partial.h"
 
 using namespace mf;
 
@@ -39,6 +40,8 @@ struct ConvP {
   long slab;
   int in_nchw, out_nchw;
   unsigned bytes1, bytes2, bytesw;  // buffer-descriptor extents (igemm path: all < 4 GiB, checked on the host)
+  double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
+  int gn_groups, gn_parts, gn_cpg;
 };
 
 // bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
@@ -49,12 +52,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + within;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED>
+template <int BM, int BN, int WM, int WN, bool SCHED, int BK>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int BK = 32, LDK = BK + 4;
+  constexpr int LDK = BK + 4;  // +4 floats: conflict-free ds_read_b128 for both BK = 32 and 64
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(!SCHED || BK == 32, "pinned schedule only for BK = 32");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int RPP = NT / 8;  // staging: 8 threads (float4 each) cover one 32-float row
+  constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
+  constexpr int RPP = NT / TPR;
   constexpr int PA = BM / RPP, PB = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
 
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   const int kc_beg = kz * p.nk_per_split;
   const int kc_end = min(p.nk, kc_beg + p.nk_per_split);
 
-  const int srow = tid >> 3, skoff = (tid & 7) * 4;
+  const int srow = tid / TPR, skoff = (tid % TPR) * 4;
 
   int a_n[PA], a_iy0[PA], a_ix0[PA];
 #pragma unroll
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   }
   int g_Cs = 0, g_coff = 0;
   __amdgpu_buffer_rsrc_t g_rs = rsw;
-  constexpr int NSEG = 16;                          // MFMA sub-groups per chunk: 4 slices x 4 k-pairs
+  constexpr int NSEG = 2 * BK / 4;                  // MFMA sub-groups per chunk: BK/8 slices x 4 k-pairs
   constexpr int PIECES = PA + PB + 1;
   constexpr int PSTRIDE = NSEG / PIECES > 0 ? NSEG / PIECES : 1;  // spread the pieces over the sub-groups
   static_assert(PIECES <= NSEG, "more gather pieces than MFMA sub-groups");
@@ -256,18 +262,56 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
   const bool add_bias = (p.splitk == 1) && p.bias != nullptr;
+  const bool do_stats = p.gn_partial != nullptr;  // host guarantees splitk == 1 and HWout % BM == 0 (tile within one sample)
+  float cs[TN], cq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
     const float bv = add_bias ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row < p.M) out[(long)row * p.Cout + col] = acc[i][j][r] + bv;
+        const float v = acc[i][j][r] + bv;
+        if (row < p.M) {
+          out[(long)row * p.Cout + col] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
       }
+    }
+    cs[j] = s1;
+    cq[j] = s2;
+  }
+  if (do_stats) {
+    // fused GroupNorm statistics (conv_blocks.py:186): per-channel sums of this tile -> LDS -> per-group fp64 partials
+    __syncthreads();  // LDS tiles are dead; reuse them: chs[WM][BN][2]
+    float* chs = smem;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = cs[j] + __shfl_xor(cs[j], 32, 64);
+      const float s2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (lane < 32) {
+        float* d = chs + ((wm * BN) + (wn * TN + j) * 32 + lane) * 2;
+        d[0] = s1;
+        d[1] = s2;
+      }
+    }
+    __syncthreads();
+    const int ngl = BN / p.gn_cpg;  // groups covered by this tile
+    if (tid < ngl) {
+      double s = 0, q = 0;
+      for (int w = 0; w < WM; ++w) {
+        const float* d = chs + (w * BN + tid * p.gn_cpg) * 2;
+        for (int c = 0; c < p.gn_cpg; ++c) { s += (double)d[2 * c]; q += (double)d[2 * c + 1]; }
+      }
+      const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
+      double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
+      o[0] = s;
+      o[1] = q;
     }
   }
 }
@@ -420,11 +464,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 }
 
 // ------------------------------------------------------------------ host-side planning
-struct TileCfg { int id, BM, BN, WM, WN; };
+struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
-    {1, 128, 128, 2, 2}, {2, 128, 64, 2, 2}, {3, 64, 128, 2, 2}, {4, 64, 64, 2, 2}, {5, 128, 32, 4, 1}, {6, 64, 32, 2, 1},
-    {7, 128, 128, 4, 2}, {8, 128, 128, 2, 4}, {9, 128, 256, 2, 4},
-    {13, 64, 128, 2, 2}, {17, 128, 128, 4, 2}, {18, 128, 128, 2, 4},  // same tiles WITH the pinned interleave (A/B only)
+    {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
+    {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32},
+    {13, 64, 128, 2, 2, 32}, {17, 128, 128, 4, 2, 32}, {18, 128, 128, 2, 4, 32},  // same tiles WITH the pinned interleave (A/B only)
+    {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
 struct Plan {
@@ -463,11 +508,12 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   pl->splitk = 1;
   pl->nk_per_split = 0;
   if (!pl->igemm) return MF_OK;
-  const int nk = d->KH * d->KW * (Cin / 32);
+  int nk = d->KH * d->KW * (Cin / 32);
   if (d->tile_hint > 0) {
     const TileCfg* c = nullptr;
     for (const auto& k : kCfgs) if (k.id == d->tile_hint) c = &k;
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
+    MF_REQUIRE(d->C1 % c->BK == 0 && d->C2 % c->BK == 0, MF_EINVAL, "conv: tile_hint %d needs channel counts divisible by %d", d->tile_hint, c->BK);
     pl->cfg = *c;
   } else {
     // From scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.txt): the 8-wave 128x128 tile (2 waves per SIMD inside
@@ -478,6 +524,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     else if (d->Cout % 64 == 0) id = 4;
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
+  nk = d->KH * d->KW * (Cin / pl->cfg.BK);
   const long tiles = (long)cdiv(pl->M, pl->cfg.BM) * (d->Cout / pl->cfg.BN);
   int sk = 1;
   if (d->splitk_hint > 0) {
@@ -492,17 +539,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED = false>
+template <int BM, int BN, int WM, int WN, bool SCHED = false, int BK = 32>
 int launch_igemm(const ConvP& p, hipStream_t s) {
-  constexpr int LDK = 36;
+  constexpr int LDK = BK + 4;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -519,6 +566,17 @@ int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int K
   return check_launch("pack_conv_weight");
 }
 
+// Number of per-sample partial records the convolution itself can emit for a following GroupNorm with G groups
+// (0: it cannot -- split-K, direct kernels, a tile straddling two samples; use mf_gn_stats_partial_f32 then).
+int mf_conv2d_gn_parts(const MfConvDesc* d, int G) {
+  Plan pl;
+  if (make_plan(d, &pl) != MF_OK || !pl.igemm || G <= 0 || d->Cout % G) return 0;
+  const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
+  if (pl.splitk > 1) return stats_lds_bytes(d->Cout / stats_slices(d->N, HW, d->Cout, G)) <= 64 * 1024 ? stats_chunks(HW) : 0;  // split-K reducer
+  if (HW % pl.cfg.BM || pl.cfg.BN % cpg) return 0;                                          // emitted by the conv epilogue
+  return HW / pl.cfg.BM;
+}
+
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
   Plan pl;
   if (make_plan(d, &pl) != MF_OK) return 0;
@@ -526,8 +584,22 @@ size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
   return (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
 }
 
+static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                       double* gn_partial, int G, const MfConvDesc* d, void* stream);
+
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
                   size_t workspace_bytes, const MfConvDesc* d, void* stream) {
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, nullptr, 0, d, stream);
+}
+
+int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
+                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream) {
+  MF_REQUIRE(gn_partial && mf_conv2d_gn_parts(d, G) > 0, MF_EUNSUPPORTED, "conv_gn: this convolution cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, gn_partial, G, d, stream);
+}
+
+static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
+                       double* gn_partial, int G, const MfConvDesc* d, void* stream) {
   Plan pl;
   int rc = make_plan(d, &pl);
   if (rc) return rc;
@@ -541,9 +613,12 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float*
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.ups = d->upsample;
   p.M = pl.M; p.K = pl.K; p.HWout = pl.Hout * pl.Wout;
   p.in_nchw = d->in_layout == MF_LAYOUT_NCHW; p.out_nchw = d->out_layout == MF_LAYOUT_NCHW;
-  p.cchunks = p.Cin / 32; p.nk = d->KH * d->KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
+  p.cchunks = pl.igemm ? p.Cin / pl.cfg.BK : 0; p.nk = d->KH * d->KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
   p.tiles_m = 0; p.tiles_n = 0; p.slab = (long)pl.M * d->Cout;
   p.bytes1 = p.bytes2 = p.bytesw = 0;
+  p.gn_partial = gn_partial; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 1;
+  p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
+  if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
   const double flops = 2.0 * pl.M * (double)d->Cout * pl.K;
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
 
@@ -600,11 +675,23 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float*
       case 13: rc = launch_igemm<64, 128, 2, 2, true>(p, s); break;
       case 17: rc = launch_igemm<128, 128, 4, 2, true>(p, s); break;
       case 18: rc = launch_igemm<128, 128, 2, 4, true>(p, s); break;
+      case 23: rc = launch_igemm<64, 128, 2, 2, false, 64>(p, s); break;
+      case 24: rc = launch_igemm<64, 64, 2, 2, false, 64>(p, s); break;
+      case 27: rc = launch_igemm<128, 128, 4, 2, false, 64>(p, s); break;
+      case 28: rc = launch_igemm<128, 128, 2, 4, false, 64>(p, s); break;
       default: set_error("conv: no tile config"); rc = MF_EINVAL;
     }
   }
   if (rc) return rc;
   if (pl.splitk > 1) {
+    if (gn_partial) {  // reduction + bias + GroupNorm partial statistics in one streaming pass
+      const int HW = pl.Hout * pl.Wout;
+      ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
+      const int slices = stats_slices(d->N, HW, d->Cout, G);
+      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(stats_chunks(HW), d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y);
+      return check_launch("splitk_reduce_stats");
+    }
     const long n4 = (long)pl.M * d->Cout / 4;
     ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
     const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);

@@ -5,61 +5,11 @@
 // combined in fp64 (a group of the VAE's 256x256 level holds 524 288 elements: E[x^2]-E[x]^2 in fp32
 // would lose the parity margin -- SURVEY §7 hard parts).
 #include "common.h"
+#include "gn_partial.h"
 
 using namespace mf;
 
 namespace {
-
-constexpr int kStatsThreads = 256;
-constexpr int kMaxChunks = 64;
-
-__host__ __device__ inline int stats_chunks(int HW) {
-  // ~>= 64 pixels per chunk, at most kMaxChunks chunks per sample
-  int c = (HW + 63) / 64;
-  return c < 1 ? 1 : (c > kMaxChunks ? kMaxChunks : c);
-}
-
-// grid (chunks, N).  Each block reduces its pixel range of sample n for all channels, then per group.
-// partial[((n*chunks + chunk)*G + g)*2 + {0,1}] = {sum, sumsq} (double)
-__global__ __launch_bounds__(kStatsThreads) void gn_stats_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int HW,
-                                                                          int C, int G) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][C][2]
-  const int chunks = gridDim.x, chunk = blockIdx.x, n = blockIdx.y;
-  const int C4 = C >> 2;
-  const int lanes_per_row = C4 < kStatsThreads ? C4 : kStatsThreads;  // threads cooperating on one pixel row
-  const int rowphases = kStatsThreads / lanes_per_row;
-  const int tid = threadIdx.x;
-  const int phase = tid / lanes_per_row, col = tid - phase * lanes_per_row;
-  const int p_per = (HW + chunks - 1) / chunks;
-  const int p0 = chunk * p_per, p1 = min(HW, p0 + p_per);
-  const float* base = x + (long)n * HW * C;
-
-  // each thread owns columns col, col+lanes_per_row, ... (only >1 when C4 > 256)
-  for (int c4 = col; c4 < C4; c4 += lanes_per_row) {
-    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    if (phase < rowphases) {
-      for (int px = p0 + phase; px < p1; px += rowphases) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (long)px * C + c4 * 4);
-        s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
-        q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
-      }
-      float* d = sh + ((long)phase * C + c4 * 4) * 2;
-      d[0] = s0; d[1] = q0; d[2] = s1; d[3] = q1; d[4] = s2; d[5] = q2; d[6] = s3; d[7] = q3;
-    }
-  }
-  __syncthreads();
-  // per group: sum over row phases and the group's channels, in double
-  const int cpg = C / G;
-  for (int g = tid; g < G; g += kStatsThreads) {
-    double s = 0, q = 0;
-    for (int ph = 0; ph < rowphases; ++ph) {
-      const float* d = sh + ((long)ph * C + g * cpg) * 2;
-      for (int c = 0; c < cpg; ++c) { s += (double)d[2 * c]; q += (double)d[2 * c + 1]; }
-    }
-    double* o = partial + (((long)n * chunks + chunk) * G + g) * 2;
-    o[0] = s; o[1] = q;
-  }
-}
 
 __global__ void gn_stats_final_kernel(const double* __restrict__ partial, float* __restrict__ stats, int NG, int G, int chunks, double count,
                                       float eps) {
@@ -117,6 +67,69 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// Same pass with the statistics FINALIZE fused in: grid (blocks_per_sample, N); every block first turns the P partial
+// records of its sample into mean / rstd for all G groups (fp64, a few KB from L2), then streams its slice of the sample.
+__global__ __launch_bounds__(256) void gn_apply_partial_kernel(const float* __restrict__ x, const double* __restrict__ partial, int P, double count,
+                                                                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ residual, const float* __restrict__ emb, long emb_stride,
+                                                                float* __restrict__ out, int HW, int C, int G, int act) {
+  extern __shared__ __attribute__((aligned(16))) float st[];  // [G][2] mean, rstd, then scratch doubles
+  const int n = blockIdx.y;
+  {
+    // finalize with all 256 threads: thread = (phase, g); phases stride over the P records, then an LDS tree over phases
+    double* red = reinterpret_cast<double*>(st + 2 * G + (2 * G & 1));  // 8-byte aligned scratch [phases][G][2]
+    const int phases = G <= 256 ? 256 / G : 1;
+    const int g = threadIdx.x % G, ph = threadIdx.x / G;
+    if (ph < phases) {
+      double s = 0, q = 0;
+      for (int c = ph; c < P; c += phases) {
+        const double* pp = partial + (((long)n * P + c) * G + g) * 2;
+        s += pp[0]; q += pp[1];
+      }
+      red[(ph * G + g) * 2] = s;
+      red[(ph * G + g) * 2 + 1] = q;
+    }
+    __syncthreads();
+    for (int gg = threadIdx.x; gg < G; gg += blockDim.x) {
+      double s = 0, q = 0;
+      for (int k = 0; k < phases; ++k) { s += red[(k * G + gg) * 2]; q += red[(k * G + gg) * 2 + 1]; }
+      const double mean = s / count;
+      double var = q / count - mean * mean;
+      if (var < 0) var = 0;
+      st[2 * gg] = (float)mean;
+      st[2 * gg + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int C4 = C >> 2, cpg = C / G;
+  const long per4 = (long)HW * C4;
+  const long base4 = (long)n * per4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int c = c4 * 4;
+    const long e = (base4 + i) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + e);
+    float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c + k) / cpg;
+      float u = (t[k] - st[2 * g]) * st[2 * g + 1];
+      if (gamma) u = u * gamma[c + k] + beta[c + k];
+      if (act == 1) u = swish_acc(u);
+      t[k] = u;
+    }
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + e);
+      t[0] += r.x; t[1] += r.y; t[2] += r.z; t[3] += r.w;
+    }
+    if (emb) {
+      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
+      t[0] += m.x; t[1] += m.y; t[2] += m.z; t[3] += m.w;
+    }
+    *reinterpret_cast<float4*>(out + e) = make_float4(t[0], t[1], t[2], t[3]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -133,14 +146,12 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
   const size_t need = mf_gn_stats_workspace_bytes(N, HW, C, G);
   MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "gn_stats: workspace %zu < %zu", workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
-  const int chunks = stats_chunks(HW);
-  const int C4 = C / 4;
-  const int lanes_per_row = C4 < kStatsThreads ? C4 : kStatsThreads;
-  const int rowphases = kStatsThreads / lanes_per_row;
-  const size_t lds = (size_t)rowphases * C * 2 * sizeof(float);
+  const int chunks = stats_chunks(HW), slices = stats_slices(N, HW, C, G);
+  const size_t lds = stats_lds_bytes(C / slices);
   MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats: C=%d too wide", C);
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
-  hipLaunchKernelGGL(gn_stats_partial_kernel, dim3(chunks, N), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G);
+  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G, 1, 0L,
+                     (const float*)nullptr, (float*)nullptr);
   int rc = check_launch("gn_stats_partial");
   if (rc) return rc;
   const int NG = N * G;
@@ -165,6 +176,51 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
                      G > 0 ? G : 1, act);
   return check_launch("gn_apply");
+}
+
+
+int mf_gn_partial_parts(int HW) { return HW > 0 ? stats_chunks(HW) : 0; }
+
+int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream) {
+  MF_REQUIRE(partial && stats && parts > 0 && N > 0 && HW > 0 && G > 0 && C % G == 0, MF_EINVAL, "gn_finalize: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int NG = N * G;
+  ProfScope ps(MF_FAM_GN_STATS, s, 0, 16.0 * NG * parts);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG + 127) / 128), dim3(128), 0, s, partial, stats, NG, G, parts, (double)HW * (C / G), eps);
+  return check_launch("gn_finalize");
+}
+
+int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int C, int G, void* stream) {
+  MF_REQUIRE(x && partial && N > 0 && HW > 0 && C > 0 && G > 0, MF_EINVAL, "gn_stats_partial: bad args");
+  MF_REQUIRE(C % 4 == 0 && C % G == 0, MF_EUNSUPPORTED, "gn_stats_partial: C=%d G=%d unsupported (need C%%4==0, C%%G==0)", C, G);
+  const int slices = stats_slices(N, HW, C, G);
+  const size_t lds = stats_lds_bytes(C / slices);
+  MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats_partial: C=%d too wide", C);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
+  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(stats_chunks(HW), N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
+                     (float*)nullptr);
+  return check_launch("gn_stats_partial");
+}
+
+int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, float eps, const float* gamma, const float* beta, const float* residual,
+                            const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream) {
+  MF_REQUIRE(x && out && partial && parts > 0 && N > 0 && HW > 0 && C > 0 && G > 0, MF_EINVAL, "gn_apply_partial: bad args");
+  MF_REQUIRE(C % 4 == 0 && C % G == 0, MF_EUNSUPPORTED, "gn_apply_partial: C=%d G=%d unsupported", C, G);
+  MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply_partial: gamma/beta must both be given or both NULL");
+  MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "gn_apply_partial: emb_stride must be a multiple of 4");
+  MF_REQUIRE(N <= 65535 && G <= 256, MF_EUNSUPPORTED, "gn_apply_partial: N or G too large");
+  hipStream_t s = (hipStream_t)stream;
+  const long per4 = (long)HW * (C / 4);
+  const double nelem = (double)N * HW * C;
+  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0)));
+  long bps = (per4 + 2047) / 2048;            // >= 8 float4 per thread: amortises the per-workgroup finalize
+  const long cap = (1024 + N - 1) / N;        // ~1024 workgroups in total
+  if (bps > cap) bps = cap;
+  if (bps < 1) bps = 1;
+  hipLaunchKernelGGL(gn_apply_partial_kernel, dim3((int)bps, N), dim3(256), (size_t)(2 * G + 2) * sizeof(float) + (size_t)(G <= 256 ? 256 / G : 1) * G * 2 * sizeof(double), s, x, partial, parts, (double)HW * (C / G), eps,
+                     gamma, beta, residual, emb, (long)emb_stride, out, HW, C, G, act);
+  return check_launch("gn_apply_partial");
 }
 
 }  // extern "C"

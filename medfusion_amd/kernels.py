@@ -19,7 +19,7 @@ def _gpu(*ts):
             continue
         if not t.is_cuda:
             raise RuntimeError("medfusion_amd: tensors must live on a ROCm device -- the product path has no CPU fallback")
-        if t.dtype != torch.float32 and t.dtype != torch.int64 and t.dtype != torch.int32 and t.dtype != torch.uint8:
+        if t.dtype not in (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8):
             raise RuntimeError(f"medfusion_amd: unsupported dtype {t.dtype}")
 
 
@@ -82,6 +82,63 @@ def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     ws = Workspace.get(need, x1.device) if need else None
     rc = lib.mf_conv2d_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, C.byref(d), stream())
     L.check(rc, "mf_conv2d_f32")
+    return out
+
+
+def conv_gn_parts(d: L.MfConvDesc, G: int) -> int:
+    """How many per-sample partial GroupNorm records this convolution emits itself (0: it cannot)."""
+    return L.load().mf_conv2d_gn_parts(C.byref(d), G)
+
+
+def conv2d_gn(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, G: int, parts: int,
+              x2: Optional[torch.Tensor] = None):
+    """Convolution + the statistics of the GroupNorm that follows (conv epilogue or split-K reducer).  -> (y NHWC, partial)"""
+    _gpu(x1, x2, w_packed, bias)
+    lib = L.load()
+    ho, wo = conv_out_hw(d)
+    out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
+    partial = torch.empty((d.N, parts, G, 2), dtype=torch.float64, device=x1.device)
+    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
+    ws = Workspace.get(need, x1.device) if need else None
+    rc = lib.mf_conv2d_gn_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(), G,
+                              C.byref(d), stream())
+    L.check(rc, "mf_conv2d_gn_f32")
+    return out, partial
+
+
+def gn_stats_partial(x: torch.Tensor, G: int):
+    """x NHWC -> (partial [N, parts, G, 2] float64 {sum, sumsq}, parts)"""
+    if x.dtype != torch.float32:
+        raise RuntimeError("gn_stats_partial: fp32 only")
+    _gpu(x)
+    n, h, w, c = x.shape
+    lib = L.load()
+    parts = lib.mf_gn_partial_parts(h * w)
+    partial = torch.empty((n, parts, G, 2), dtype=torch.float64, device=x.device)
+    L.check(lib.mf_gn_stats_partial_f32(x.data_ptr(), partial.data_ptr(), n, h * w, c, G, stream()), "mf_gn_stats_partial_f32")
+    return partial, parts
+
+
+def gn_finalize(partial: torch.Tensor, parts: int, HW: int, C: int, G: int, eps: float = 1e-5) -> torch.Tensor:
+    """partial [N, parts, G, 2] -> stats [N, G, 2] = (mean, rstd)"""
+    _gpu(partial)
+    n = partial.shape[0]
+    stats = torch.empty((n, G, 2), dtype=torch.float32, device=partial.device)
+    L.check(L.load().mf_gn_finalize_f32(partial.data_ptr(), parts, stats.data_ptr(), n, HW, C, G, eps, stream()), "mf_gn_finalize_f32")
+    return stats
+
+
+def gn_apply_partial(x: torch.Tensor, partial: torch.Tensor, parts: int, gamma, beta, G: int, eps: float = 1e-5, act: int = 1,
+                     residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """finalise mean/rstd from the partial sums and apply norm + affine + act + residual + emb in one pass"""
+    _gpu(x, gamma, beta, residual, emb)
+    n, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = L.load().mf_gn_apply_partial_f32(x.data_ptr(), partial.data_ptr(), parts, eps, _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride,
+                                          out.data_ptr(), n, h * w, c, G, act, stream())
+    L.check(rc, "mf_gn_apply_partial_f32")
     return out
 
 

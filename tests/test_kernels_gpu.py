@@ -44,13 +44,15 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 18, 23, 24, 27, 28])
 def test_conv_igemm(dev, case, tile):
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, stride, ups = case
-    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32, 7: 128, 8: 128, 9: 256}.get(tile, 32)
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32, 7: 128, 8: 128, 9: 256, 13: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128}.get(tile, 32)
     if tile and co % bn:
         pytest.skip("tile does not divide Cout")
+    if tile > 20 and (c1 % 64 or c2 % 64):
+        pytest.skip("BK=64 tiles need channel counts divisible by 64")
     x = _rand(f"cx{case}", (n, c1, h, w))
     x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
     wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
@@ -156,6 +158,42 @@ def test_groupnorm_swish_residual_emb(dev, case):
     # no-affine / no-act / in-place variants
     y2 = K.gn_apply(xd, stats, None, None, g, 0)
     assert relerr(K.nhwc_to_nchw(y2), F.group_norm(x.double(), g, None, None, 1e-5).float()) < 3e-6
+
+
+@pytest.mark.parametrize("case", [(2, 16, 8, 64, 0, 128, 3, 32, 8), (16, 8, 8, 128, 128, 256, 3, 32, 0), (2, 32, 32, 64, 0, 64, 3, 8, 4), (1, 16, 16, 128, 0, 128, 1, 8, 8)])
+def test_conv_fused_groupnorm_statistics(dev, case):
+    """mf_conv2d_gn_f32 (stats from the conv epilogue or the split-K reducer) + mf_gn_apply_partial_f32 == conv -> GroupNorm -> Swish + residual."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, g, tile = case
+    x = _rand(f"fx{case}", (n, c1, h, w))
+    x2 = _rand(f"fy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"fw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"fb{case}", (co,), 0.1) + 0.5
+    res = _rand(f"fr{case}", (n, co, h, w))
+    gamma, beta = 1 + 0.2 * _rand(f"fg{case}", (co,)), _rand(f"fz{case}", (co,), 0.1)
+    pad = R.monai_padding(k, 1)
+    yc = _conv_ref(x, x2, wt, b, 1, pad, 0).double()
+    gn = F.group_norm(yc, g, gamma.double(), beta.double(), 1e-5)
+    want = (gn * torch.sigmoid(gn) + res.double()).float()
+    for sk in (0, 1, 2):
+        d = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=tile, splitk_hint=sk)
+        parts = K.conv_gn_parts(d, g)
+        xd = K.nchw_to_nhwc(x.to(dev))
+        x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+        wp = K.pack_conv_weight(wt.to(dev))
+        if parts > 0:
+            y, partial = K.conv2d_gn(xd, wp, b.to(dev), d, g, parts, x2=x2d)
+        else:
+            y = K.conv2d(xd, wp, b.to(dev), d, x2=x2d)
+            partial, parts = K.gn_stats_partial(y, g)
+        ref_sum = yc.reshape(n, g, -1).sum(-1)
+        assert relerr(partial[..., 0].sum(1), ref_sum) < 1e-5, (case, sk, parts)
+        assert relerr(partial[..., 1].sum(1), (yc * yc).reshape(n, g, -1).sum(-1)) < 1e-5
+        out = K.gn_apply_partial(y, partial, parts, gamma.to(dev), beta.to(dev), g, 1e-5, 1, K.nchw_to_nhwc(res.to(dev)))
+        assert relerr(K.nhwc_to_nchw(out), want) < 1e-5, (case, sk, parts)
+        stats = K.gn_finalize(partial, parts, h * w, co, g)   # hot-path form: finalize kernel + plain apply
+        out2 = K.gn_apply(y, stats, gamma.to(dev), beta.to(dev), g, 1, K.nchw_to_nhwc(res.to(dev)))
+        assert relerr(K.nhwc_to_nchw(out2), want) < 1e-5, (case, sk, parts)
 
 
 def test_groupnorm_large_group_fp64_combine(dev):
