@@ -52,12 +52,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + within;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED, int BK>
+template <int BM, int BN, int WM, int WN, bool SCHED, int BK, bool PP, int DBG>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int LDK = BK + 4;  // +4 floats: conflict-free ds_read_b128 for both BK = 32 and 64
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(!SCHED || BK == 32, "pinned schedule only for BK = 32");
+  static_assert(!PP || (NT == 512 && !SCHED), "ping-pong needs 8 waves (two per SIMD)");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
@@ -212,9 +213,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     f32x4 fa[2][TM], fb[2][TN];                                                                                      \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
-    if (DO_STORE) MF_LDS_STORE(buf ^ 1);                                                                             \
+    if ((DO_STORE) && DBG != 2) MF_LDS_STORE(buf ^ 1);                                                               \
     if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if ((DO_LOAD) && !SCHED) { MF_ADVANCE(); MF_GLOAD(KC); }                                                         \
+    if ((DO_LOAD) && !SCHED && DBG != 1) { MF_ADVANCE(); MF_GLOAD(KC); }                                                       \
     _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
       const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
       if (kk + 1 < BK / 8) {                                                                                         \
@@ -248,6 +249,53 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
 
   int buf = 0;
   int kc = kc_beg;
+  if (PP) {
+    // Ping-pong schedule for 8-wave workgroups (PMC: with a common barrier per chunk BOTH waves of every SIMD are in their
+    // memory phase at the same time and the matrix pipe idles ~25 %).  Waves 0-3 (one per SIMD) and their SIMD partners
+    // 4-7 alternate roles every barrier interval:
+    //   interval 2k   : A = MFMAs of chunk k          | B = LDS-store its share of chunk k+1, issue its loads of chunk k+2
+    //   interval 2k+1 : A = store k+1 / load k+2      | B = MFMAs of chunk k
+    // so one wave per SIMD is always inside its MFMA segment.  buf[(k+1)&1] last held chunk k-1, whose readers finished in
+    // intervals 2k-2 (A) and 2k-1 (B); chunk k+1 is complete after interval 2k+1, first read in interval 2k+2.
+#define MF_PP_COMPUTE()                                                                                              \
+  {                                                                                                                  \
+    const float* Ab = Aw + buf * BM * LDK;                                                                           \
+    const float* Bb = Bw + buf * BN * LDK;                                                                           \
+    f32x4 fa[2][TM], fb[2][TN];                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
+      const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
+      if (kk + 1 < BK / 8) {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+            fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+            fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                          \
+      }                                                                                                              \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);      \
+    }                                                                                                                \
+  }
+#define MF_PP_MEMORY()                                                                                               \
+  {                                                                                                                  \
+    if (kc + 1 < kc_end) MF_LDS_STORE(buf ^ 1);                                                                      \
+    if (kc + 2 < kc_end) {                                                                                           \
+      MF_ADVANCE();                                                                                                  \
+      MF_GLOAD(kc + 2);                                                                                              \
+    }                                                                                                                \
+  }
+    const bool groupB = __builtin_amdgcn_readfirstlane(wave) >= 4;
+    __syncthreads();  // chunk kc_beg visible
+    for (; kc < kc_end; ++kc) {
+      if (groupB) { MF_PP_MEMORY(); } else { MF_PP_COMPUTE(); }
+      __syncthreads();
+      if (groupB) { MF_PP_COMPUTE(); } else { MF_PP_MEMORY(); }
+      __syncthreads();
+      buf ^= 1;
+    }
+  } else {
   for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
     MF_COMPUTE(true, true, kc + 2);
   }
@@ -257,6 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     } else {
       MF_COMPUTE(false, false, 0);
     }
+  }
   }
 
   // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -469,6 +518,8 @@ const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
     {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32},
     {13, 64, 128, 2, 2, 32}, {17, 128, 128, 4, 2, 32}, {18, 128, 128, 2, 4, 32},  // same tiles WITH the pinned interleave (A/B only)
+    {37, 128, 128, 4, 2, 32}, {38, 128, 128, 2, 4, 32}, {39, 128, 256, 2, 4, 32},  // ping-pong schedule
+    {48, 128, 128, 2, 4, 32}, {49, 128, 128, 2, 4, 32},  // ABLATION ONLY (wrong results): tile 8 without global loads / without LDS stores
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
@@ -539,17 +590,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED = false, int BK = 32>
+template <int BM, int BN, int WM, int WN, bool SCHED = false, int BK = 32, bool PP = false, int DBG = 0>
 int launch_igemm(const ConvP& p, hipStream_t s) {
   constexpr int LDK = BK + 4;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK, PP, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK, PP, DBG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -675,6 +726,11 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
       case 13: rc = launch_igemm<64, 128, 2, 2, true>(p, s); break;
       case 17: rc = launch_igemm<128, 128, 4, 2, true>(p, s); break;
       case 18: rc = launch_igemm<128, 128, 2, 4, true>(p, s); break;
+      case 37: rc = launch_igemm<128, 128, 4, 2, false, 32, true>(p, s); break;
+      case 38: rc = launch_igemm<128, 128, 2, 4, false, 32, true>(p, s); break;
+      case 39: rc = launch_igemm<128, 256, 2, 4, false, 32, true>(p, s); break;
+      case 48: rc = launch_igemm<128, 128, 2, 4, false, 32, false, 1>(p, s); break;
+      case 49: rc = launch_igemm<128, 128, 2, 4, false, 32, false, 2>(p, s); break;
       case 23: rc = launch_igemm<64, 128, 2, 2, false, 64>(p, s); break;
       case 24: rc = launch_igemm<64, 64, 2, 2, false, 64>(p, s); break;
       case 27: rc = launch_igemm<128, 128, 4, 2, false, 64>(p, s); break;

@@ -32,14 +32,14 @@ def stream() -> int:
 
 
 class Workspace:
-    """Grow-only scratch owned by torch (the library never allocates).  One per device; launches on one
+    """Grow-only scratch owned by torch (the library never allocates).  One per (device, stream): launches on one
     stream are serialised so sharing is safe.  Grown only outside graph capture (warm-up run does it)."""
 
     _bufs = {}
 
     @classmethod
     def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)  # per stream: concurrent streams must not share scratch
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():

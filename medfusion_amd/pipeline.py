@@ -61,6 +61,7 @@ class DiffusionPipeline(nn.Module):
         self.do_input_centering = do_input_centering
         self.estimate_variance = estimate_variance
         self.clip_x0 = clip_x0
+        self.batch_cfg = True  # classifier-free guidance as one 2B-row UNet call (same arithmetic per row)
         self.use_ema = use_ema
         if use_ema:
             self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
@@ -87,6 +88,12 @@ class DiffusionPipeline(nn.Module):
             if self.estimate_variance:
                 raise RuntimeError("estimate_variance with guidance_scale != 1 raises in the reference too "
                                    "(diffusion_pipeline.py:243-249 never chunks `pred`); use guidance_scale=1")
+            if self.batch_cfg and not self.use_self_conditioning:
+                # both passes of diffusion_pipeline.py:242-243 as ONE UNet call over 2B rows (rows are independent):
+                # rows [0,B) = un-guided (condition = un_cond, possibly None), rows [B,2B) = guided.
+                pred2 = est.forward_cfg_pair(x_t, t, condition, un_cond)
+                B = x_t.shape[0]
+                return pred2[B:], pred2[:B], None
             pred_uncond, _ = est(x_t, t, condition=un_cond, self_cond=self_cond)  # un-guided pass FIRST (Q6)
             pred_cond, _ = est(x_t, t, condition=condition, self_cond=self_cond)
             return pred_cond, pred_uncond, None

@@ -163,10 +163,12 @@ class UNet(nn.Module):
             self._emb_cache_key = key
         return self._emb_w, self._emb_b
 
-    def embed(self, t, condition):
+    def embed(self, t, condition, emb_override=None):
         """Global embedding [B,E] and the lookup giving every module its embedding (unet2.py:229-241)."""
         time_emb = None if t is None else self.time_embedder(t)
-        if condition is None or self.cond_embedder is None:
+        if emb_override is not None:
+            emb = emb_override
+        elif condition is None or self.cond_embedder is None:
             emb = time_emb
         elif time_emb is None:
             emb = self.cond_embedder(condition)
@@ -185,14 +187,30 @@ class UNet(nn.Module):
 
         return emb, lookup
 
+    @torch.no_grad()
+    def forward_cfg_pair(self, x_t, t, condition, un_cond):
+        """Classifier-free-guidance pair in one pass: returns y [2B,...] with rows [0,B) = forward(x_t, t, un_cond) and
+        rows [B,2B) = forward(x_t, t, condition).  Per-row arithmetic is the same as two separate calls."""
+        B = x_t.shape[0]
+        x2 = torch.cat([x_t, x_t], dim=0)            # plumbing: 2 x 8192*B floats
+        t2 = torch.cat([t, t], dim=0)
+        time_emb = self.time_embedder(t2)              # [2B, E]
+        if self.cond_embedder is not None:
+            tab = self.cond_embedder.embedding.weight
+            if un_cond is not None:
+                K.embedding_add(tab, un_cond, time_emb[:B])
+            K.embedding_add(tab, condition, time_emb[B:])
+        h, _ = self.features(x2, None, None, None, emb_override=time_emb)
+        return self.outc(h)
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def features(self, x_t, t=None, condition=None, self_cond=None):
+    def features(self, x_t, t=None, condition=None, self_cond=None, emb_override=None):
         """Everything of unet2.py:222-264 up to (not including) the 1x1 out convolution: (h NHWC, y_ver)."""
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.UNet runs on a ROCm device only (no CPU fallback)")
         x_t = x_t.contiguous()
-        _, lookup = self.embed(t, condition)
+        _, lookup = self.embed(t, condition, emb_override)
         if self.use_self_conditioning:
             # SURVEY Q11: reference concatenates zeros if self_cond is None else x_t ITSELF (unet2.py:245)
             a = K.nchw_to_nhwc(x_t)

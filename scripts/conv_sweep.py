@@ -83,9 +83,9 @@ def main():
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            for tile in (3, 4, 7, 8, 23, 24, 27, 28):
-                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 13: 128, 17: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
-                if tile > 20 and (c1 % 64 or c2 % 64):
+            for tile in (4, 7, 8, 24, 37, 38, 39):
+                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 13: 128, 17: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256}[tile]
+                if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
                     continue
                 if co % bn:
                     continue

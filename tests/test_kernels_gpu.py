@@ -44,14 +44,14 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 18, 23, 24, 27, 28])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 18, 23, 24, 27, 28, 37, 38, 39])
 def test_conv_igemm(dev, case, tile):
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, stride, ups = case
-    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32, 7: 128, 8: 128, 9: 256, 13: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128}.get(tile, 32)
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 5: 32, 6: 32, 7: 128, 8: 128, 9: 256, 13: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256}.get(tile, 32)
     if tile and co % bn:
         pytest.skip("tile does not divide Cout")
-    if tile > 20 and (c1 % 64 or c2 % 64):
+    if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
         pytest.skip("BK=64 tiles need channel counts divisible by 64")
     x = _rand(f"cx{case}", (n, c1, h, w))
     x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None

@@ -252,6 +252,19 @@ def test_conditional_3class_cfg3_shape(dev):
 
 
 @torch.no_grad()
+def test_batched_cfg_pair_equals_two_passes(dev):
+    """Classifier-free guidance as ONE 2B-row UNet call (default) vs the reference's two sequential calls (un-guided first)."""
+    pipe = build_product_pipe(R.tiny_unet_kwargs(3, ["none", "none", "linear", "spatial"]), R.tiny_vae_kwargs(), "pipe_cfgpair", dev)
+    cond = torch.tensor([2, 0, 1], device=dev)
+    for un_cond in (None, torch.tensor([0, 1, 2], device=dev)):
+        outs = []
+        for flag in (True, False):
+            pipe.batch_cfg = flag
+            outs.append(pipe.sample(3, (8, 8, 8), condition=cond, un_cond=un_cond, guidance_scale=3.0, steps=3, use_ddim=True, noise=M.PhiloxDeviceNoise(5)))
+        assert relerr(outs[0], outs[1]) < 1e-5
+
+
+@torch.no_grad()
 def test_ddpm_1000_schedule_cfg4_prefix(dev, published):
     """configs[3]: non-DDIM posterior sampling; `steps` < T takes the FIRST timesteps (Q5).  6 iterations vs oracle."""
     ora, pipe = published
