@@ -40,9 +40,12 @@ def build_pipeline(dev, classes):
     from oracle import synth as S     # ... and the deterministic synthetic weight fill (inputs, not compute)
     from tests.util import to_product_kwargs
 
-    pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, M.UNet, None, R.published_scheduler_kwargs(),
-                               to_product_kwargs(R.published_unet_kwargs(classes)), estimator_objective="x_T", clip_x0=False)
-    pipe.latent_embedder = M.VAE(**R.published_vae_kwargs(8))
+    from medfusion_amd.utils import no_init
+
+    with no_init():  # every tensor is overwritten by the synthetic fill below
+        pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, M.UNet, None, R.published_scheduler_kwargs(),
+                                   to_product_kwargs(R.published_unet_kwargs(classes)), estimator_objective="x_T", clip_x0=False)
+        pipe.latent_embedder = M.VAE(**R.published_vae_kwargs(8))
     S.synth_state_dict(pipe.noise_estimator, "published.unet.")
     S.synth_state_dict(pipe.latent_embedder, "published.vae.")
     return pipe.to(dev).eval()
@@ -87,6 +90,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--ddim-steps", type=int, default=None, help="override the number of denoise iterations (non-headline)")
+    ap.add_argument("--graph", action="store_true", help="replay the denoise iteration as a captured hipGraph (default for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -109,6 +113,8 @@ def main():
     pipe = build_pipeline(dev, wl["classes"])
     cond = (torch.arange(n_global, device=dev) % wl["classes"]) if wl["classes"] else None
     kw = dict(steps=wl["steps"], use_ddim=wl["use_ddim"])
+    if args.graph or args.workload == "cfg4":
+        kw["use_graph"] = True
     if cond is not None:
         kw.update(guidance_scale=wl["guidance"], un_cond=None)
 
@@ -137,9 +143,10 @@ def main():
 
     roof = None
     if not args.no_roofline and rank == 0:
-        # live launch timing of the dominant kernel (conv_igemm) over a few denoise iterations on this rank's shard
+        # live launch timing of the dominant kernel (conv_igemm): one more full step of the SAME workload with every launch
+        # bracketed by hipEvents on its stream (mf_prof_*); rocprofv3 --kernel-trace of this command sees the same mix
         with K.prof() as p:
-            pipe.sample(B, wl["latent"], condition=None if cond is None else cond[:B], noise=M.PhiloxDeviceNoise(7), steps=min(6, wl["steps"]),
+            pipe.sample(B, wl["latent"], condition=None if cond is None else cond[:B], noise=M.PhiloxDeviceNoise(7), steps=wl["steps"],
                         use_ddim=wl["use_ddim"], **({} if cond is None else dict(guidance_scale=wl["guidance"], un_cond=None)))
         tab = p.table()
         ms, n, fl, _ = tab["conv_igemm"]

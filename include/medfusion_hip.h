@@ -153,6 +153,8 @@ typedef struct MfSchedArgs {
   int64_t n;                 /* elements */
 } MfSchedArgs;
 int mf_sched_step_f32(const MfSchedArgs* a, void* stream);
+/* out[0..n) = table[step] with step = *step_dev (or `step`): `t.expand(B)` of diffusion_pipeline.py:294 inside a captured graph */
+int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int32_t step, float* out, int n, void* stream);
 /* *counter += inc (one thread); lets a captured graph advance its own step index. */
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream);
 

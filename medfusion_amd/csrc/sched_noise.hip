@@ -69,6 +69,12 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
   }
 }
 
+__global__ void broadcast_from_table_kernel(const float* __restrict__ table, const int32_t* __restrict__ step_dev, int step, float* __restrict__ out, int n) {
+  const int st = step_dev ? *step_dev : step;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = table[st];
+}
+
 __global__ void counter_add_kernel(int32_t* c, int32_t inc) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
 }
@@ -127,6 +133,12 @@ int mf_sched_step_f32(const MfSchedArgs* a, void* stream) {
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(sched_step_kernel, dim3((int)blocks), dim3(256), 0, s, *a);
   return check_launch("sched_step");
+}
+
+int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int32_t step, float* out, int n, void* stream) {
+  MF_REQUIRE(table && out && n > 0, MF_EINVAL, "broadcast_from_table: bad args");
+  hipLaunchKernelGGL(broadcast_from_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, step_dev, step, out, n);
+  return check_launch("broadcast_from_table");
 }
 
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream) {

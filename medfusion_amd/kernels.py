@@ -214,6 +214,12 @@ def sched_step(args: L.MfSchedArgs) -> None:
     L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
 
 
+def broadcast_from_table(table: torch.Tensor, step_dev: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _gpu(table, step_dev, out)
+    L.check(L.load().mf_broadcast_from_table_f32(table.data_ptr(), step_dev.data_ptr(), 0, out.data_ptr(), out.numel(), stream()), "mf_broadcast_from_table_f32")
+    return out
+
+
 def counter_add(counter: torch.Tensor, inc: int = 1) -> None:
     _gpu(counter)
     L.check(L.load().mf_counter_add_i32(counter.data_ptr(), inc, stream()), "mf_counter_add_i32")

@@ -131,7 +131,8 @@ class DiffusionPipeline(nn.Module):
 
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
-    def denoise(self, x_t, steps=None, condition=None, use_ddim=True, noise: Optional[NoiseSource] = None, trace=None, decode=True, **kwargs):
+    def denoise(self, x_t, steps=None, condition=None, use_ddim=True, noise: Optional[NoiseSource] = None, trace=None, decode=True, use_graph=False,
+                **kwargs):
         """diffusion_pipeline.py:278-310.  kwargs: guidance_scale, un_cond, cold_diffusion (forwarded to forward()
         by the reference); `eta` raises like the reference's forward() would (Q2)."""
         if "eta" in kwargs:
@@ -146,6 +147,8 @@ class DiffusionPipeline(nn.Module):
             raise ValueError("Unknown Objective")
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
+        if use_graph and trace is not None:
+            raise ValueError("use_graph=True cannot record a trace (the captured step is replayed, nothing returns to the host)")
         sch = self.noise_scheduler
         dev = x_t.device
         B = x_t.shape[0]
@@ -156,30 +159,93 @@ class DiffusionPipeline(nn.Module):
             noise = default_noise()
             noise.begin(B, dev)
         rev = list(reversed(timesteps))
-        t_all = torch.tensor(rev, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, B).contiguous()  # t.expand(B) per iteration (Q7)
         objective = 0 if self.estimator_objective == "x_T" else 1
         x_t = x_t.contiguous().clone()
-        n_post = torch.empty_like(x_t)
-        n_ddim = torch.empty_like(x_t)
-        x0 = torch.empty_like(x_t)
-        self_cond = None
-        for i in range(len(rev)):
-            pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond)
-            noise.draw(tuple(x_t.shape), out=n_post)          # gaussian_scheduler.py:99 -- drawn on every iteration (Q3)
-            ddim = recs[i].mode == 1
-            if ddim:
-                noise.draw(tuple(x_t.shape), out=n_ddim)      # diffusion_pipeline.py:303
-            a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
-                              None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if ddim else None, 0,
-                              x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), None, i, objective, int(bool(self.clip_x0)),
-                              float(guidance_scale), x_t.numel())
-            K.sched_step(a)
-            self_cond = x0 if self.use_self_conditioning else None  # only None-ness matters downstream (Q11)
-            if trace is not None:
-                trace.append((x0.clone(), x_t.clone()))
+        if use_graph:
+            self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective)
+        else:
+            t_all = torch.tensor(rev, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, B).contiguous()  # t.expand(B) per iteration (Q7)
+            n_post = torch.empty_like(x_t)
+            n_ddim = torch.empty_like(x_t)
+            x0 = torch.empty_like(x_t)
+            self_cond = None
+            for i in range(len(rev)):
+                pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond)
+                noise.draw(tuple(x_t.shape), out=n_post)          # gaussian_scheduler.py:99 -- drawn on every iteration (Q3)
+                ddim = recs[i].mode == 1
+                if ddim:
+                    noise.draw(tuple(x_t.shape), out=n_ddim)      # diffusion_pipeline.py:303
+                a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
+                                  None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if ddim else None, 0,
+                                  x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), None, i, objective, int(bool(self.clip_x0)),
+                                  float(guidance_scale), x_t.numel())
+                K.sched_step(a)
+                self_cond = x0 if self.use_self_conditioning else None  # only None-ness matters downstream (Q11)
+                if trace is not None:
+                    trace.append((x0.clone(), x_t.clone()))
         if decode and self.latent_embedder is not None:
             x_t = self.latent_embedder.decode(x_t)
         return x_t
+
+    def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective):
+        """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]).  Everything the
+        reference reads on the host each iteration (t, alphas_cumprod[t], the t==0 test, the RNG state) is indexed by a
+        DEVICE step counter: `t` is broadcast from a device table, the scheduler scalars come from the MfSchedStep table,
+        the Philox draw index is draw_base + stride*step, and the graph advances the counter itself.  The last DDIM
+        iteration still fills the (unused) DDIM noise buffer: counter-based draws do not shift any other draw."""
+        from .noise import PhiloxDeviceNoise
+
+        if not isinstance(noise, PhiloxDeviceNoise):
+            raise RuntimeError("use_graph=True needs the device Philox noise source (a host generator cannot be captured)")
+        dev, B = x_t.device, x_t.shape[0]
+        t_table = torch.tensor(rev, dtype=torch.float32, device=dev)
+        step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_cur = torch.empty(B, dtype=torch.float32, device=dev)
+        n_post, n_ddim, x0 = torch.empty_like(x_t), torch.empty_like(x_t), torch.empty_like(x_t)
+        stride = 2 if use_ddim else 1
+        base = noise.draw_index  # draws consumed so far (x_T)
+        clip, g = int(bool(self.clip_x0)), float(guidance_scale)
+
+        def body():
+            K.broadcast_from_table(t_table, step_dev, t_cur)
+            pred, pred_uncond, pred_var = self._predict(x_t, t_cur, condition, None if not self.use_self_conditioning else x0, g, un_cond)
+            noise.draw_indexed(n_post, base, stride, step_dev)
+            if use_ddim:
+                noise.draw_indexed(n_ddim, base + 1, stride, step_dev)
+            a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
+                              None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if use_ddim else None, 0,
+                              x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), step_dev.data_ptr(), 0, objective, clip, g, x_t.numel())
+            K.sched_step(a)
+            K.counter_add(step_dev, 1)
+            return pred  # keep alive until the end of capture
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # Q11: with self-conditioning the first call sees self_cond=None -> run it eagerly in that form
+            if self.use_self_conditioning:
+                K.broadcast_from_table(t_table, step_dev, t_cur)
+                pred, pu, pv = self._predict(x_t, t_cur, condition, None, g, un_cond)
+                noise.draw_indexed(n_post, base, stride, step_dev)
+                if use_ddim:
+                    noise.draw_indexed(n_ddim, base + 1, stride, step_dev)
+                a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pu is None else pu.data_ptr(), None if pv is None else pv.data_ptr(),
+                                  n_post.data_ptr(), n_ddim.data_ptr() if use_ddim else None, 0, x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(),
+                                  step_dev.data_ptr(), 0, objective, clip, g, x_t.numel())
+                K.sched_step(a)
+                K.counter_add(step_dev, 1)
+            else:
+                body()  # eager warm-up iteration 0: sizes every workspace / packs weights on THIS stream
+            done = 1
+            if len(rev) > done:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    keep = body()
+                for _ in range(done, len(rev)):
+                    graph.replay()
+                del keep
+        torch.cuda.current_stream(dev).wait_stream(side)
+        noise.draw_index = base + stride * len(rev)
 
     @torch.no_grad()
     def sample(self, num_samples, img_size, condition=None, noise: Optional[NoiseSource] = None, shard=None, **kwargs):

@@ -264,6 +264,24 @@ def test_batched_cfg_pair_equals_two_passes(dev):
         assert relerr(outs[0], outs[1]) < 1e-5
 
 
+@pytest.mark.parametrize("use_ddim,cond", [(True, False), (False, False), (True, True)])
+@torch.no_grad()
+def test_hipgraph_captured_step_equals_eager(dev, use_ddim, cond):
+    """configs[3]: the denoise iteration captured once as a hipGraph and replayed (device step counter drives t, the scheduler
+    table and the Philox draw index) must give bit-identical latents to the eager loop."""
+    pipe = build_product_pipe(R.tiny_unet_kwargs(3, "none"), R.tiny_vae_kwargs(), "pipe_graph", dev)
+    kw = dict(steps=9, use_ddim=use_ddim)
+    if cond:
+        kw.update(condition=torch.tensor([2, 0, 1, 1], device=dev), guidance_scale=4.0)
+    eager = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), **kw)
+    graph = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), use_graph=True, **kw)
+    assert torch.equal(eager, graph)
+    again = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), use_graph=True, **kw)
+    assert torch.equal(graph, again)
+    with pytest.raises(RuntimeError, match="Philox"):
+        pipe.sample(2, (8, 8, 8), noise=oracle_noise(1), use_graph=True, steps=3)
+
+
 @torch.no_grad()
 def test_ddpm_1000_schedule_cfg4_prefix(dev, published):
     """configs[3]: non-DDIM posterior sampling; `steps` < T takes the FIRST timesteps (Q5).  6 iterations vs oracle."""
