@@ -158,6 +158,13 @@ int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int
 /* *counter += inc (one thread); lets a captured graph advance its own step index. */
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream);
 
+/* Per-row scaled combination: out[b][:] = clamp?((a[b]*x[b][:] + c[b]*y[b][:]) / d[b]); y, a, c, d optional (NULL).
+ * The scheduler's tensor-level API with a timestep PER ROW (gaussian_scheduler.py:61-77 estimate_x_t, :104-107, :119-131)
+ * and the lerp of DiffusionPipeline.interpolate (diffusion_pipeline.py:329); coefficient rows are gathered on the host like
+ * `extract()` (scheduler_base.py:43-46).  Bit-exact vs ATen's elementwise chain. */
+int mf_rows_axpby_f32(const float* x, const float* y, const float* a, const float* c, const float* d, float* out, int B,
+                      int64_t per_row, int do_clamp, float lo, float hi, void* stream);
+
 /* ------------------------------------------------------------------ noise
  * Counter-based standard normals (Philox-4x32-10 + Box-Muller), shard-invariant: element quad q of sample
  * (sample_offset + b) in draw `draw` depends only on (seed, draw, sample index, q).  Stands in for
@@ -188,6 +195,12 @@ int mf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, vo
 /* DiagonalGaussianDistribution (latent_embedders.py:22-27): z = mean + exp(0.5*clamp(logvar,-30,20)) * noise,
  * moments NCHW [N][2C][HW] -> z [N][C][HW] */
 int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float* z, int N, int C, int HW, void* stream);
+
+/* Image egress on the device: NCHW float -> NHWC uint8.
+ * mode 0: scripts/helpers/sample_dataset.py:44-53  clip(-1,1) -> (x+1)/2*255 -> astype(uint8)   (bit-exact vs numpy)
+ * mode 1: scripts/sample.py:49-51 + torchvision save_image(normalize=True, scale_each=True): (x+1)/2, clamp(0,1), per-image
+ *         min-max, mul(255).add(0.5).clamp(0,255).to(uint8); minmax_ws = 2*N floats of caller scratch. */
+int mf_image_egress_u8(const float* x_nchw, uint8_t* out_nhwc, float* minmax_ws, int N, int C, int H, int W, int mode, void* stream);
 
 /* ------------------------------------------------------------------ built-in launch timing (bench / roofline)
  * When enabled every launch is bracketed by hipEvents on its own stream and attributed to a kernel family.

@@ -9,7 +9,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmedfusion_hip.so"
-SOURCES = ["api.hip", "conv.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip"]
+SOURCES = ["api.hip", "conv.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +24,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", HERE.parent / "include" / "medfusion_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gn_partial.h", HERE.parent / "include" / "medfusion_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 

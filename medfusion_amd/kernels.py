@@ -210,6 +210,34 @@ def philox_normal(out: torch.Tensor, seed: int, draw: int, sample_offset: int = 
     return out
 
 
+def rows_axpby(x: torch.Tensor, a: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None, c: Optional[torch.Tensor] = None,
+               d: Optional[torch.Tensor] = None, clamp: Optional[tuple] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b] = clamp((a[b]*x[b] + c[b]*y[b]) / d[b]); a, c, d are [B] fp32 device vectors (or None)."""
+    _gpu(x, a, y, c, d)
+    x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+    b = x.shape[0]
+    if out is None:
+        out = torch.empty_like(x)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    rc = L.load().mf_rows_axpby_f32(x.data_ptr(), _ptr(y), _ptr(a), _ptr(c), _ptr(d), out.data_ptr(), b, x.numel() // b, int(clamp is not None),
+                                    float(lo), float(hi), stream())
+    L.check(rc, "mf_rows_axpby_f32")
+    return out
+
+
+def image_to_uint8(x_nchw: torch.Tensor, normalize_each: bool = False) -> torch.Tensor:
+    """[N,C,H,W] float in ~[-1,1] -> [N,H,W,C] uint8 on the device (mode 0: sample_dataset.py; mode 1: sample.py + save_image)."""
+    _gpu(x_nchw)
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    ws = torch.empty((n, 2), dtype=torch.float32, device=x.device) if normalize_each else None
+    L.check(L.load().mf_image_egress_u8(x.data_ptr(), out.data_ptr(), _ptr(ws), n, c, h, w, int(normalize_each), stream()), "mf_image_egress_u8")
+    return out
+
+
 def sched_step(args: L.MfSchedArgs) -> None:
     L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
 

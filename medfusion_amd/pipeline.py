@@ -107,12 +107,23 @@ class DiffusionPipeline(nn.Module):
     def forward(self, x_t, t, condition=None, self_cond=None, guidance_scale=1.0, cold_diffusion=False, un_cond=None, noise=None):
         """One reverse step like diffusion_pipeline.py:232-275 -> (x_t_prior, x_0, x_T, self_cond).
         `noise`: the posterior draw of gaussian_scheduler.py:99 (tensor); N(0,1) from the default source if None."""
-        if cold_diffusion:
-            raise NotImplementedError("cold_diffusion is off the sampling path (SURVEY §8a S2)")
         if self.estimator_objective not in ("x_T", "x_0"):
             raise ValueError("Unknown Objective")
         sch = self.noise_scheduler
         pred, pred_uncond, pred_var = self._predict(x_t, t, condition, self_cond, guidance_scale, un_cond)
+        if cold_diffusion:  # off the hot loop: composed from the per-row scheduler API (gaussian_scheduler.py:88-93)
+            if pred_var is not None:
+                raise NotImplementedError("cold_diffusion with a learned variance head")
+            if pred_uncond is not None:
+                g = torch.full((x_t.shape[0],), float(guidance_scale), device=x_t.device)
+                m1 = torch.full((x_t.shape[0],), -1.0, device=x_t.device)
+                pred = K.rows_axpby(pred_uncond, None, K.rows_axpby(pred, None, pred_uncond, m1), g)   # pu + g*(pc - pu)
+            if self.estimator_objective == "x_0":
+                prior, x0 = sch.estimate_x_t_prior_from_x_0(x_t, t, pred, clip_x0=self.clip_x0, cold_diffusion=True)
+                xT = sch.estimate_x_T(x_t, x_0=pred, t=t, clip_x0=self.clip_x0)
+                return prior, x0, xT, xT
+            prior, x0 = sch.estimate_x_t_prior_from_x_T(x_t, t, pred, clip_x0=self.clip_x0, cold_diffusion=True)
+            return prior, x0, pred, x0
         rec = sch.step_records([sch._uniform_t(t)], use_ddim=False)[0]
         table = sch.upload_records([rec], x_t.device)
         if noise is None:
@@ -270,6 +281,23 @@ class DiffusionPipeline(nn.Module):
         return self.denoise(x_T, condition=condition, noise=noise, **kwargs)
 
     @torch.no_grad()
-    def interpolate(self, img1, img2, i=None, condition=None, lam=0.5, **kwargs):
-        """diffusion_pipeline.py:320-332 (note: passes `i` positionally as `steps`, as the reference does)."""
-        raise NotImplementedError("interpolate needs estimate_x_t (training-side forward diffusion): SURVEY §8f row 3, not built yet")
+    def interpolate(self, img1, img2, i=None, condition=None, lam=0.5, noise: Optional[NoiseSource] = None, **kwargs):
+        """diffusion_pipeline.py:320-332: diffuse both inputs to timestep i, lerp, denoise with `i` passed as `steps`.
+        NB the reference method ALWAYS raises (it forwards `clip_x0=` to estimate_x_t, which has no such parameter); this
+        implements its evident intent (what oracle/restate.py restates).  `i=None` raises TypeError like the reference's
+        `torch.full(shape, None)`.  Noise draws: #0 and #1 = the two x_T of estimate_x_t, then the denoise loop's."""
+        assert img1.shape == img2.shape, "Image 1 and 2 must have equal shape"
+        if i is None:
+            raise TypeError("full() received an invalid combination of arguments - got (torch.Size, NoneType, device=torch.device)")
+        if noise is None:
+            noise = default_noise()
+        B = img1.shape[0]
+        noise.begin(B, img1.device)
+        t = torch.full(img1.shape[:1], i, device=img1.device)
+        sch = self.noise_scheduler
+        img1_t = sch.estimate_x_t(img1, t=t, noise=noise.draw(tuple(img1.shape)))
+        img2_t = sch.estimate_x_t(img2, t=t, noise=noise.draw(tuple(img2.shape)))
+        a = torch.full((B,), 1 - lam, dtype=torch.float32, device=img1.device)
+        c = torch.full((B,), lam, dtype=torch.float32, device=img1.device)
+        img = K.rows_axpby(img1_t, a, img2_t, c)  # (1 - lam) * img1_t + lam * img2_t
+        return self.denoise(img, i, condition, noise=noise, **kwargs)

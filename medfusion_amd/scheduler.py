@@ -133,49 +133,90 @@ class GaussianNoiseScheduler(BasicNoiseScheduler):
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
         return raw.to(device)
 
-    # ------------------------------------------------------------------ tensor-level API (row S2), shared t per call
+    # ------------------------------------------------------------------ tensor-level API, t PER ROW
+    # Coefficient rows are gathered on the host like `extract()` (scheduler_base.py:43-46) and applied by
+    # mf_rows_axpby_f32; every method is bit-identical to the reference's elementwise chain on the same inputs.
+    def _rows(self, name: str, t: torch.Tensor, device, negate: bool = False) -> torch.Tensor:
+        v = self.host_tables()[name].gather(0, t.detach().to("cpu", torch.long).reshape(-1))
+        return (-v if negate else v).to(device)
+
     def _uniform_t(self, t) -> int:
         tv = t.detach().cpu().reshape(-1)
         if not bool((tv == tv[0]).all()):
-            raise NotImplementedError("HIP scheduler methods take one timestep for the whole batch (the sampling loop's t.expand(B), Q7)")
+            raise NotImplementedError("this fused path takes one timestep for the whole batch (the sampling loop's t.expand(B), Q7)")
         return int(tv[0])
 
-    def _one_step(self, x_t, pred, t, objective, clip_x0, noise_post=None):
-        rec = self.step_records([self._uniform_t(t)], use_ddim=False)[0]
-        table = self.upload_records([rec], x_t.device)
-        x_t = x_t.contiguous()
-        pred = pred.contiguous()
-        out, x0, xT = torch.empty_like(x_t), torch.empty_like(x_t), torch.empty_like(x_t)
-        a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None, None, None if noise_post is None else noise_post.data_ptr(), None, 0,
-                          out.data_ptr(), x0.data_ptr(), xT.data_ptr(), table.data_ptr(), None, 0, objective, int(bool(clip_x0)), 1.0, x_t.numel())
-        K.sched_step(a)
-        return out, x0, xT
+    @classmethod
+    def _clip_x_0(cls, x_0):
+        """gaussian_scheduler.py:138-151: static thresholding to [-1, 1]"""
+        return K.rows_axpby(x_0, clamp=(-1.0, 1.0))
+
+    def estimate_x_t(self, x_0, t, x_T=None, noise: Optional[torch.Tensor] = None):
+        """gaussian_scheduler.py:61-77: rows with t<0 return x_0, t>=T return x_T, else sqrt(ac)*x_0 + sqrt(1-ac)*x_T."""
+        if x_T is None:
+            x_T = noise if noise is not None else self.x_final(x_0)
+        tc = t.detach().to("cpu", torch.long).reshape(-1)
+        tb = self.host_tables()
+        idx = tc.clamp(0, self.T - 1)
+        a = torch.where(tc < 0, torch.ones(()), torch.where(tc >= self.T, torch.zeros(()), tb["sqrt_alphas_cumprod"].gather(0, idx)))
+        c = torch.where(tc < 0, torch.zeros(()), torch.where(tc >= self.T, torch.ones(()), tb["sqrt_one_minus_alphas_cumprod"].gather(0, idx)))
+        return K.rows_axpby(x_0, a.to(x_0.device), x_T, c.to(x_0.device))
 
     def estimate_x_0(self, x_t, x_T, t, clip_x0=True):
         """gaussian_scheduler.py:119-124"""
-        return self._one_step(x_t, x_T, t, 0, clip_x0)[1]
+        dev = x_t.device
+        return K.rows_axpby(x_t, self._rows("sqrt_recip_alphas_cumprod", t, dev), x_T, self._rows("sqrt_recipm1_alphas_cumprod", t, dev, negate=True),
+                            clamp=(-1.0, 1.0) if clip_x0 else None)
 
     def estimate_x_T(self, x_t, x_0, t, clip_x0=True):
         """gaussian_scheduler.py:127-131"""
-        return self._one_step(x_t, x_0, t, 1, clip_x0)[2]
+        dev = x_t.device
+        x_0 = self._clip_x_0(x_0) if clip_x0 else x_0
+        minus_one = torch.full((x_t.shape[0],), -1.0, device=dev)
+        return K.rows_axpby(x_t, self._rows("sqrt_recip_alphas_cumprod", t, dev), x_0, minus_one, self._rows("sqrt_recipm1_alphas_cumprod", t, dev))
+
+    def estimate_mean_t(self, x_t, x_0, t):
+        """gaussian_scheduler.py:104-107"""
+        dev = x_t.device
+        return K.rows_axpby(x_0, self._rows("posterior_mean_coef1", t, dev), x_t, self._rows("posterior_mean_coef2", t, dev))
+
+    def estimate_variance_t(self, t, ndim, log=True, var_scale=0, eps=1e-20):
+        """gaussian_scheduler.py:110-116 (scalar var_scale): [B,1,...] tensor on t's device, evaluated with the reference's ops."""
+        tb = self.host_tables()
+        tc = t.detach().to("cpu", torch.long).reshape(-1)
+        mn, mx = self.extract(tb["posterior_variance"], tc, ndim), self.extract(tb["betas"], tc, ndim)
+        if log:
+            mn, mx = torch.log(mn.clamp(min=eps)), torch.log(mx.clamp(min=eps))
+        return (var_scale * mx + (1 - var_scale) * mn).to(t.device)
 
     def estimate_x_t_prior_from_x_T(self, x_t, t, x_T, use_log=True, clip_x0=True, var_scale=0, cold_diffusion=False, noise=None):
-        """gaussian_scheduler.py:80-82 (+ :85-101).  `noise`: the posterior draw (tensor); N(0,1) Philox if None."""
-        return self._prior(x_t, t, x_T, 0, use_log, clip_x0, var_scale, cold_diffusion, noise)
+        """gaussian_scheduler.py:80-82"""
+        x_0 = self.estimate_x_0(x_t, x_T, t, clip_x0)
+        return self.estimate_x_t_prior_from_x_0(x_t, t, x_0, use_log, clip_x0, var_scale, cold_diffusion, noise)
 
     def estimate_x_t_prior_from_x_0(self, x_t, t, x_0, use_log=True, clip_x0=True, var_scale=0, cold_diffusion=False, noise=None):
-        return self._prior(x_t, t, x_0, 1, use_log, clip_x0, var_scale, cold_diffusion, noise)
-
-    def _prior(self, x_t, t, pred, objective, use_log, clip_x0, var_scale, cold_diffusion, noise):
-        if cold_diffusion or not use_log or not (isinstance(var_scale, (int, float)) and var_scale == 0):
-            raise NotImplementedError("HIP scheduler: cold_diffusion / use_log=False / tensor var_scale are off the sampling path")
+        """gaussian_scheduler.py:85-101.  `noise`: the posterior draw (tensor); N(0,1) from the default device source if None."""
+        x_0 = self._clip_x_0(x_0) if clip_x0 else x_0
+        if cold_diffusion:  # https://arxiv.org/abs/2208.09392, :88-93
+            x_T_est = self.estimate_x_T(x_t, x_0, t)
+            x_t_est = self.estimate_x_t(x_0, t, x_T=x_T_est)
+            x_t_prior = self.estimate_x_t(x_0, t - 1, x_T=x_T_est)
+            m1 = torch.full((x_t.shape[0],), -1.0, device=x_t.device)
+            noise_t = K.rows_axpby(x_t_est, None, x_t_prior, m1)        # x_t_est - x_t_prior
+            return K.rows_axpby(x_t, None, noise_t, m1), x_0             # x_t - noise_t
+        if torch.is_tensor(var_scale):
+            raise NotImplementedError("tensor var_scale (learned variance) runs through the fused step kernel of DiffusionPipeline")
+        mean = self.estimate_mean_t(x_t, x_0, t)
+        tc = t.detach().to("cpu", torch.long).reshape(-1)
+        variance = self.estimate_variance_t(tc, 1, use_log, var_scale)
+        std = torch.exp(0.5 * variance) if use_log else torch.sqrt(variance)
+        std[tc == 0] = 0.0
         if noise is None:
-            from .noise import default_noise
-            src = default_noise()
-            src.begin(x_t.shape[0], x_t.device)
-            noise = src.draw(tuple(x_t.shape))
-        out, x0, _ = self._one_step(x_t, pred, t, objective, clip_x0, noise_post=noise.contiguous())
-        return out, x0
+            noise = self.x_final(x_t)
+        return K.rows_axpby(mean, None, noise, std.to(x_t.device)), x_0
+
+    def sample(self, x_0):
+        raise NotImplementedError("scheduler.sample() draws training timesteps (scheduler_base.py:19-23): training is out of scope")
 
     @classmethod
     def x_final(cls, x):

@@ -355,3 +355,45 @@ def test_no_cpu_fallback():
     u = M.UNet(**dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[32, 32, 64, 128], time_embedder_kwargs={"emb_dim": 64}, deep_supervision=False))
     with pytest.raises(RuntimeError, match="no CPU"):
         u(torch.zeros((1, 8, 8, 8)), torch.zeros((1,)))
+
+
+def test_scheduler_tensor_api_per_row_t_bit_exact(dev):
+    """SURVEY §8a row S2 with a DIFFERENT timestep per row (training / interpolate callers), bit-exact vs the oracle."""
+    import medfusion_amd as M
+    osch = R.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    psch = M.GaussianNoiseScheduler(**R.published_scheduler_kwargs()).to(dev)
+    shape = (5, 8, 4, 4)
+    x0, xT, xt, nz = (_rand(f"api{k}", shape) for k in range(4))
+    t = torch.tensor([0, 17, 999, 500, 3])
+    D = lambda z: z.to(dev)
+    assert torch.equal(psch.estimate_x_t(D(x0), D(torch.tensor([-1, 0, 999, 1000, 42])), D(xT)).cpu(), osch.estimate_x_t(x0, torch.tensor([-1, 0, 999, 1000, 42]), xT))
+    for clip in (True, False):
+        assert torch.equal(psch.estimate_x_0(D(xt), D(xT), D(t), clip).cpu(), osch.estimate_x_0(xt, xT, t, clip))
+        assert torch.equal(psch.estimate_x_T(D(xt), D(x0), D(t), clip).cpu(), osch.estimate_x_T(xt, x0, t, clip))
+        osch.noise_fn = lambda like: nz
+        for fn in ("estimate_x_t_prior_from_x_T", "estimate_x_t_prior_from_x_0"):
+            pa, pb = getattr(psch, fn)(D(xt), D(t), D(xT), clip_x0=clip, noise=D(nz))
+            oa, ob = getattr(osch, fn)(xt, t, xT, clip_x0=clip)
+            assert torch.equal(pa.cpu(), oa) and torch.equal(pb.cpu(), ob), (fn, clip)
+        tc = torch.tensor([5, 17, 999, 500, 3])  # cold diffusion uses t-1: keep t >= 1
+        pa, pb = psch.estimate_x_t_prior_from_x_0(D(xt), D(tc), D(x0), clip_x0=clip, cold_diffusion=True)
+        oa, ob = osch.estimate_x_t_prior_from_x_0(xt, tc, x0, clip_x0=clip, cold_diffusion=True)
+        assert torch.equal(pa.cpu(), oa) and torch.equal(pb.cpu(), ob)
+    assert torch.equal(psch.estimate_mean_t(D(xt), D(x0), D(t)).cpu(), osch.estimate_mean_t(xt, x0, t))
+    assert torch.equal(psch.estimate_variance_t(D(t), 4).cpu(), osch.estimate_variance_t(t, 4))
+
+
+def test_image_egress_uint8(dev):
+    from medfusion_amd import kernels as K
+    x = _rand("egress", (3, 3, 20, 24), 0.9)
+    x[0, 0, 0, :4] = torch.tensor([-1.5, 1.5, 1.0, -1.0])
+    got = K.image_to_uint8(x.to(dev)).cpu().numpy()
+    img = x.numpy().clip(-1, 1)
+    img = (img + 1) / 2 * 255                      # scripts/helpers/sample_dataset.py:46-47 verbatim arithmetic
+    want = np.moveaxis(img, 1, -1).astype(np.uint8)
+    assert np.array_equal(got, want)
+    got1 = K.image_to_uint8(x.to(dev), normalize_each=True).cpu()
+    r = ((x + 1) / 2).clamp(0, 1)                  # scripts/sample.py:49-50, then torchvision norm_ip + save_image
+    r = torch.stack([(b.clamp(min=float(b.min()), max=float(b.max())) - b.min()) / max(float(b.max() - b.min()), 1e-5) for b in r])
+    want1 = r.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert torch.equal(got1, want1)

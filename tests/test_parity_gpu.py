@@ -290,3 +290,34 @@ def test_ddpm_1000_schedule_cfg4_prefix(dev, published):
     want = ora.sample(1, (8, 16, 16), steps=6, use_ddim=False)
     got = pipe.sample(1, (8, 16, 16), steps=6, use_ddim=False, noise=oracle_noise(55))
     assert relerr(got, want) < TOL
+
+
+@torch.no_grad()
+def test_interpolate_vs_oracle(dev):
+    """DiffusionPipeline.interpolate (the reference method itself raises: it forwards clip_x0= to
+    estimate_x_t; the oracle restates its evident intent)."""
+    ora = build_oracle_pipe(R.tiny_unet_kwargs(2, "none"), R.tiny_vae_kwargs(), "pipe_interp")
+    pipe = build_product_pipe(R.tiny_unet_kwargs(2, "none"), R.tiny_vae_kwargs(), "pipe_interp", dev)
+    a, b = S.synth_input("interp_a", (2, 8, 8, 8)), S.synth_input("interp_b", (2, 8, 8, 8))
+    cond = torch.tensor([1, 0])
+    ora.set_noise_fn(S.PhiloxNoise(61))
+    want = ora.interpolate(a, b, i=6, condition=cond, lam=0.3, guidance_scale=2.0)
+    got = pipe.interpolate(a.to(dev), b.to(dev), i=6, condition=cond.to(dev), lam=0.3, guidance_scale=2.0, noise=oracle_noise(61))
+    assert relerr(got, want) < TOL
+    with pytest.raises(TypeError):
+        pipe.interpolate(a.to(dev), b.to(dev))
+
+
+@torch.no_grad()
+def test_forward_single_step_api_incl_cold_diffusion(dev):
+    """DiffusionPipeline.forward (diffusion_pipeline.py:232-275) as a stand-alone call, regular and cold-diffusion branches."""
+    ora = build_oracle_pipe(R.tiny_unet_kwargs(3, "none"), None, "pipe_fwd", clip_x0=True)
+    pipe = build_product_pipe(R.tiny_unet_kwargs(3, "none"), None, "pipe_fwd", dev, clip_x0=True)
+    x, nz = S.synth_input("fwd_x", (3, 8, 8, 8)), S.synth_input("fwd_n", (3, 8, 8, 8))
+    t, cond = torch.full((3,), 400), torch.tensor([0, 2, 1])
+    for cold in (False, True):
+        ora.set_noise_fn(lambda like: nz)
+        want = ora(x, t, cond, guidance_scale=2.5, cold_diffusion=cold)
+        got = pipe(x.to(dev), t.to(dev), cond.to(dev), guidance_scale=2.5, cold_diffusion=cold, noise=nz.to(dev))
+        for w, g in zip(want[:3], got[:3]):
+            assert relerr(g, w) < TOL, cold
