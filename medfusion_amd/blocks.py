@@ -139,17 +139,30 @@ class BasicBlock(nn.Module):
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
-            nm = self.norm
-            y, partial, parts = self.conv(x, in_layout=in_layout, gn_groups=nm.num_groups)
-            n, h, w, c = y.shape
-            stats = K.gn_finalize(partial, parts, h * w, c, nm.num_groups, nm.eps)
-            return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+            return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride)
         y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         if not (self.has_act or residual is not None or emb is not None):
             return y
         if out_layout != L.LAYOUT_NHWC:
             raise RuntimeError("act/residual epilogue needs NHWC")
         return K.gn_apply(y, None, None, None, 1, int(self.has_act), residual, emb, emb_stride, out=y)
+
+
+def _basicblock_conv_and_stats(self, x, in_layout=L.LAYOUT_NHWC):
+    """conv (+ fused GroupNorm partial statistics) -> (y, partial, parts)"""
+    return self.conv(x, in_layout=in_layout, gn_groups=self.norm.num_groups)
+
+
+def _basicblock_finish(self, y_partial, residual=None, emb=None, emb_stride=0):
+    y, partial, parts = y_partial
+    nm = self.norm
+    n, h, w, c = y.shape
+    stats = K.gn_finalize(partial, parts, h * w, c, nm.num_groups, nm.eps)
+    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+
+
+BasicBlock.conv_and_stats = _basicblock_conv_and_stats
+BasicBlock.finish = _basicblock_finish
 
 
 class BasicResBlock(nn.Module):
@@ -166,10 +179,37 @@ class BasicResBlock(nn.Module):
         if isinstance(self.conv_res, nn.Identity):
             if isinstance(x, (tuple, list)) or in_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("identity residual needs a single NHWC input")
-            res = x
-        else:
+            return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+        if not SIDE_STREAM_RESIDUAL:
             res = self.conv_res(x, in_layout=in_layout)
-        return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+            return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+        # The 1x1 residual conv and the 3x3 conv read the same input and are independent: run the small one on a side
+        # stream so its ramp-up/drain overlaps the big one (fork/join; works under graph capture too).
+        cur = torch.cuda.current_stream()
+        side = _side_stream(cur.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            res = self.conv_res(x, in_layout=in_layout)
+        y_partial = self.basic_block.conv_and_stats(x, in_layout=in_layout)
+        cur.wait_stream(side)
+        for t in (_split(x)):
+            if t is not None:
+                t.record_stream(side)
+        res.record_stream(cur)
+        return self.basic_block.finish(y_partial, residual=res, emb=emb, emb_stride=emb_stride)
+
+
+SIDE_STREAM_RESIDUAL = False  # experiment: measured SLOWER on MI355X (13.26 vs 13.52 img/s at cfg2, scripts/ab_side_stream.py) -> off
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    s = _SIDE.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE[key] = s
+    return s
 
 
 class _EmbBlock(nn.Module):

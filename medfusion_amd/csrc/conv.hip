@@ -16,6 +16,7 @@
 //  * conv_direct_kernel: any shape / NCHW edges (Cin = 8|3, Cout = 8|3|16): <0.2 % of the FLOPs.
 #include "common.h"
 #include "gn_partial.h"
+#include <cstdlib>
 
 using namespace mf;
 
@@ -239,11 +240,24 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   }
 
   if (kc_beg < kc_end) {
+    // cold start: put the loads of chunk 0 AND chunk 1 in flight before waiting for either (one HBM/TLB latency, not two)
     MF_GLOAD(kc_beg);
-    MF_LDS_STORE(0);
+    f32x4 ra0[PA], rb0[PB];
+#pragma unroll
+    for (int q = 0; q < PA; ++q) ra0[q] = ra[q];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) rb0[q] = rb[q];
     if (kc_beg + 1 < kc_end) {
       MF_ADVANCE();
       MF_GLOAD(kc_beg + 1);
+    }
+    {
+      float* a_ = As + srow * LDK + skoff;
+      float* b_ = Bs + srow * LDK + skoff;
+#pragma unroll
+      for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra0[q];
+#pragma unroll
+      for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb0[q];
     }
   }
 
@@ -445,12 +459,12 @@ __global__ void conv_direct_kernel(const ConvP p) {
 // Small-Cin convolution (UNet in_conv 8->256, VAE inc_dec 8->512, VAE inc 3->64): K = KH*KW*Cin <= 160.
 // A persistent block keeps a transposed weight tile W^T[k][co] (co <= 256) in LDS, then walks pixel groups:
 // the im2col patch of 16 pixels goes to LDS (broadcast reads), lane = output channel => coalesced NHWC stores.
-constexpr int kSmallPix = 16, kSmallCo = 256, kSmallMaxK = 160;
+constexpr int kSmallPix = 16, kSmallCo = 256, kSmallMaxK = 160, kSmallPG = 4;
 
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int groups) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wT = sm;                                   // [K][kSmallCo]
-  float* patch = sm + (size_t)p.K * kSmallCo;       // [kSmallPix][K]
+  float* patch = sm + (size_t)p.K * kSmallCo;       // [kSmallPG][kSmallPix][K]
   const int tid = threadIdx.x;
   const int co0 = blockIdx.y * kSmallCo;
   const int nco = min(kSmallCo, p.Cout - co0);
@@ -458,15 +472,23 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int g
     const int co = i / p.K, k = i - co * p.K;
     wT[k * kSmallCo + co] = p.w[(long)(co0 + co) * p.K + k];
   }
-  const float bias = (p.bias && tid < nco) ? p.bias[co0 + tid] : 0.f;
-  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
-    const int m0 = g * kSmallPix;
+  // thread = (pixel group pg of 4, channel quad cq of 64): 4 output channels x 16 pixels in registers
+  const int pg = tid >> 6, cq = tid & 63;
+  const bool active = cq * 4 < nco;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active && p.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = p.bias[co0 + cq * 4 + j];
+  }
+  const int PK = kSmallPix * p.K;
+  for (int g0 = blockIdx.x * kSmallPG; g0 < groups; g0 += gridDim.x * kSmallPG) {
     __syncthreads();
-    for (int i = tid; i < kSmallPix * p.K; i += 256) {
-      const int px = i / p.K, k = i - px * p.K;
+    for (int i = tid; i < kSmallPG * PK; i += 256) {
+      const int gq = i / PK, r = i - gq * PK;
+      const int px = r / p.K, k = r - px * p.K;
       const int tap = k / p.Cin, ci = k - tap * p.Cin;
       const int ky = tap / p.KW, kx = tap - ky * p.KW;
-      const int m = m0 + px;
+      const int m = (g0 + gq) * kSmallPix + px;
       float v = 0.f;
       if (m < p.M) {
         const int n = m / p.HWout, rem = m - n * p.HWout;
@@ -482,18 +504,26 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int g
       patch[i] = v;
     }
     __syncthreads();
-    if (tid < nco) {
-      float acc[kSmallPix];
+    const int m0 = (g0 + pg) * kSmallPix;
+    if (active && m0 < p.M) {
+      float acc[kSmallPix][4];
 #pragma unroll
-      for (int q = 0; q < kSmallPix; ++q) acc[q] = bias;
+      for (int q = 0; q < kSmallPix; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][j] = bias4[j];
+      const float* pp = patch + pg * PK;
       for (int k = 0; k < p.K; ++k) {
-        const float wv = wT[k * kSmallCo + tid];
+        const float4 wv = *reinterpret_cast<const float4*>(wT + k * kSmallCo + cq * 4);
 #pragma unroll
-        for (int q = 0; q < kSmallPix; ++q) acc[q] = fmaf(patch[q * p.K + k], wv, acc[q]);
+        for (int q = 0; q < kSmallPix; ++q) {
+          const float xv = pp[q * p.K + k];
+          acc[q][0] = fmaf(xv, wv.x, acc[q][0]); acc[q][1] = fmaf(xv, wv.y, acc[q][1]);
+          acc[q][2] = fmaf(xv, wv.z, acc[q][2]); acc[q][3] = fmaf(xv, wv.w, acc[q][3]);
+        }
       }
 #pragma unroll
       for (int q = 0; q < kSmallPix; ++q)
-        if (m0 + q < p.M) p.y[(long)(m0 + q) * p.Cout + co0 + tid] = acc[q];
+        if (m0 + q < p.M) *reinterpret_cast<float4*>(p.y + (long)(m0 + q) * p.Cout + co0 + cq * 4) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
     }
   }
 }
@@ -571,8 +601,16 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     // ONE workgroup: half the LDS/L2 traffic of two 64x128 workgroups) is best or within 2 % of best for every shape with
     // Cout % 128 == 0; 64x64 for the 64-channel VAE level.  Split-K (below) tops the grid up to >= 512 workgroups.
     int id = 6;
-    if (d->Cout % 128 == 0 && pl->M >= 128) id = 8;
-    else if (d->Cout % 64 == 0) id = 4;
+    static const int variant = [] { const char* e = getenv("MF_PLANNER"); return e ? atoi(e) : 0; }();  // tuning knob (A/B runs)
+    const bool c64 = d->C1 % 64 == 0 && d->C2 % 64 == 0;
+    const long t128 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
+    if (d->Cout % 128 == 0 && pl->M >= 128) {
+      id = 8;
+      if (variant == 1 && t128 < 256) id = c64 ? 24 : 4;                 // B: small tiles whenever 128x128 leaves CUs empty
+      if (variant == 2 && t128 < 256 && t128 >= 128) id = c64 ? 24 : 4;  // C: ... only at the 16x16 level
+    } else if (d->Cout % 64 == 0) {
+      id = (variant != 0 && c64) ? 24 : 4;
+    }
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
   nk = d->KH * d->KW * (Cin / pl->cfg.BK);
@@ -673,17 +711,19 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   const double flops = 2.0 * pl.M * (double)d->Cout * pl.K;
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
 
-  if (!pl.igemm && !p.out_nchw && p.Cin <= 16 && pl.K <= kSmallMaxK && d->Cout % 64 == 0) {
+  if (!pl.igemm && !p.out_nchw && p.Cin <= 16 && pl.K <= kSmallMaxK && d->Cout % 64 == 0 &&
+      ((size_t)pl.K * kSmallCo + (size_t)kSmallPG * kSmallPix * pl.K) * sizeof(float) <= 150 * 1024) {
     ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
     const int groups = cdiv(pl.M, kSmallPix);
     const int cotiles = cdiv(d->Cout, kSmallCo);
-    const size_t lds = ((size_t)pl.K * kSmallCo + (size_t)kSmallPix * pl.K) * sizeof(float);
+    const size_t lds = ((size_t)pl.K * kSmallCo + (size_t)kSmallPG * kSmallPix * pl.K) * sizeof(float);
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr = true;
     }
-    int gx = groups < 1024 ? groups : 1024;
+    int gx = cdiv(groups, kSmallPG);
+    if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
     return check_launch("conv_smallcin");
   }

@@ -321,3 +321,60 @@ def test_forward_single_step_api_incl_cold_diffusion(dev):
         got = pipe(x.to(dev), t.to(dev), cond.to(dev), guidance_scale=2.5, cold_diffusion=cold, noise=nz.to(dev))
         for w, g in zip(want[:3], got[:3]):
             assert relerr(g, w) < TOL, cold
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 8, 8), (5, 8, 12, 20), (33, 8, 8, 8), (2, 8, 4, 4)])
+@torch.no_grad()
+def test_ragged_and_nonsquare_shapes_vs_oracle(dev, shape):
+    """Edge shapes: batch 1, a batch that leaves ragged GEMM tiles (33), non-square latents, the smallest legal latent (4x4)."""
+    ora = build_oracle_pipe(R.tiny_unet_kwargs(2, "none"), R.tiny_vae_kwargs(), "pipe_ragged")
+    pipe = build_product_pipe(R.tiny_unet_kwargs(2, "none"), R.tiny_vae_kwargs(), "pipe_ragged", dev)
+    b = shape[0]
+    x = S.synth_input(f"rag{shape}", shape)
+    t = torch.full((b,), 123)
+    c = torch.arange(b) % 2
+    want, _ = ora.noise_estimator(x, t, c)
+    got, _ = pipe.noise_estimator(x.to(dev), t.to(dev), c.to(dev))
+    assert relerr(got, want) < TOL
+    assert relerr(pipe.latent_embedder.decode(x.to(dev)), ora.latent_embedder.decode(x)) < TOL
+    ora.set_noise_fn(S.PhiloxNoise(71))
+    want = ora.sample(b, shape[1:], steps=2, use_ddim=True)
+    got = pipe.sample(b, shape[1:], steps=2, use_ddim=True, noise=oracle_noise(71))
+    assert relerr(got, want) < TOL
+
+
+@torch.no_grad()
+def test_four_channel_latent_model_family(dev):
+    """The eye / colon Medfusion models use in_ch = out_ch = emb_channels = 4 (streamlit/pages/eye.py:34, colon.py:36)."""
+    ukw = R.tiny_unet_kwargs(2, "none")
+    ukw.update(in_ch=4, out_ch=4)
+    vkw = R.tiny_vae_kwargs(emb_channels=4)
+    ora = build_oracle_pipe(ukw, vkw, "pipe_4ch")
+    pipe = build_product_pipe(ukw, vkw, "pipe_4ch", dev)
+    ora.set_noise_fn(S.PhiloxNoise(81))
+    cond = torch.tensor([1, 0])
+    want = ora.sample(2, (4, 16, 16), condition=cond, guidance_scale=1.0, steps=3, use_ddim=True)
+    got = pipe.sample(2, (4, 16, 16), condition=cond.to(dev), guidance_scale=1.0, steps=3, use_ddim=True, noise=oracle_noise(81))
+    assert relerr(got, want) < TOL
+    img = S.synth_input("img4", (2, 3, 32, 32), 0.5)
+    nz = S.PhiloxNoise(82)
+    ora.latent_embedder.quantizer.noise_fn = lambda shape, device: nz(torch.empty(shape))
+    assert relerr(pipe.latent_embedder.encode(img.to(dev), noise=oracle_noise(82)), ora.latent_embedder.encode(img)) < TOL
+
+
+@torch.no_grad()
+def test_cfg5_512px_shape_properties(dev, published):
+    """configs[4]: latent (8,64,64) -> 512x512 on the published widths.  One UNet evaluation + decode vs the oracle at B=1
+    (the oracle needs ~10 s on CPU), then row independence at B=4."""
+    ora, pipe = published
+    x = S.synth_input("cfg5_x", (1, 8, 64, 64))
+    t = torch.tensor([250])
+    want, _ = ora.noise_estimator(x, t, None)
+    got, _ = pipe.noise_estimator(x.to(dev), t.to(dev), None)
+    assert relerr(got, want) < TOL
+    img = pipe.latent_embedder.decode(x.to(dev))
+    assert img.shape == (1, 3, 512, 512)
+    assert relerr(img, ora.latent_embedder.decode(x)) < TOL
+    full = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False)
+    one = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False, shard=(2, 4))
+    assert relerr(one, full[2:3]) < 1e-5
