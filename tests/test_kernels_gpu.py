@@ -319,7 +319,8 @@ def test_sched_step_learned_variance(dev):
         assert relerr(out, prior) < 1e-6  # expf on device vs CPU
 
 
-@pytest.mark.parametrize("case", [(2, 4, 64, 64, 8), (2, 8, 100, 100, 32), (1, 3, 256, 256, 32), (2, 8, 64, 1, 4), (1, 8, 70, 130, 128)])
+@pytest.mark.parametrize("case", [(2, 4, 64, 64, 8), (2, 8, 100, 100, 32), (1, 3, 256, 256, 32), (2, 8, 64, 1, 4), (1, 8, 70, 130, 128), (2, 8, 1024, 1024, 32),
+                                  (1, 8, 256, 256, 64), (3, 2, 33, 47, 16), (1, 8, 64, 64, 4), (2, 8, 16, 16, 8)])
 def test_attention(dev, case):
     from medfusion_amd import kernels as K
     b, h, nq, nk, d = case
