@@ -51,7 +51,8 @@ typedef struct MfConvDesc {
   int32_t KH, KW;          /* 1x1 or 3x3 */
   int32_t stride;          /* 1 or 2 */
   int32_t pad;             /* MONAI get_padding(k, s) = int((k - s + 1) / 2) */
-  int32_t upsample;        /* 1: nearest x2 of the input is fused into the gather */
+  int32_t upsample;        /* 1: nearest x2 of the input fused into the gather; 2: the same op in its SUB-PIXEL form (4 phase-specific
+                              2x2 convs on the low-res tensor, 4/9 of the MACs; weights from mf_pack_upconv_weight_f32) */
   int32_t in_layout;       /* layout of x1 (NCHW only with C2 == 0) */
   int32_t out_layout;      /* layout of y */
   int32_t tile_hint;       /* 0 = auto; else forces an implicit-GEMM tile config (tuning/tests) */
@@ -60,6 +61,10 @@ typedef struct MfConvDesc {
 } MfConvDesc;
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
+/* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],
+ * each phase kernel = sum of the 3x3 taps that land on the same source pixel.  mf_conv2d_subpixel_ok: can `d` (upsample = 2) run so? */
+int mf_pack_upconv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
+int mf_conv2d_subpixel_ok(const MfConvDesc* d);
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
 /* y = conv(x1 (++ x2 on channels), w) + bias.  bias may be NULL.  workspace >= mf_conv2d_workspace_bytes. */
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,

@@ -43,9 +43,10 @@ def _split(x: Act):
 class _Packed:
     """Lazily packed device copy of a conv weight, invalidated by in-place parameter updates."""
 
-    def __init__(self):
+    def __init__(self, subpixel: bool = False):
         self._key = None
         self._w = None
+        self._subpixel = subpixel
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
         key = (weight.data_ptr(), weight._version, weight.device)
@@ -53,9 +54,12 @@ class _Packed:
             w = weight.detach()
             if w.dim() == 3:  # Conv1d [O, I, 1]
                 w = w.unsqueeze(-1)
-            self._w = K.pack_conv_weight(w)
+            self._w = K.pack_upconv_weight(w) if self._subpixel else K.pack_conv_weight(w)
             self._key = key
         return self._w
+
+
+SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 
 
 class Conv(nn.Module):
@@ -67,6 +71,7 @@ class Conv(nn.Module):
         self.weight, self.bias = holder.weight, holder.bias  # default torch init, reference key names
         self.in_ch, self.out_ch, self.k, self.stride, self.pad, self.upsample = in_ch, out_ch, kernel_size, stride, padding, int(upsample)
         self._packed = _Packed()
+        self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
 
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0):
@@ -84,10 +89,14 @@ class Conv(nn.Module):
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
             d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout)
+            if self.upsample and SUBPIXEL_UPSAMPLE and rows is None:
+                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout)
+                if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
+                    d = d2
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
             self._descs[key] = ent
         d, parts = ent
-        wp = self._packed.get(self.weight)
+        wp = self._packed_sub.get(self.weight) if d.upsample == 2 else self._packed.get(self.weight)
         b = self.bias
         if rows is not None:  # output-channel slice (learned-variance head split)
             wp, b = wp[rows], b[rows]

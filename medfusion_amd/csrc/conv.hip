@@ -41,6 +41,7 @@ struct ConvP {
   long slab;
   int in_nchw, out_nchw;
   unsigned bytes1, bytes2, bytesw;  // buffer-descriptor extents (igemm path: all < 4 GiB, checked on the host)
+  int subpix, hw_src;               // sub-pixel form of nearest-x2 + 3x3: 4 phase-specific 2x2 convs on the low-res source
   double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
   int gn_groups, gn_parts, gn_cpg;
 };
@@ -92,11 +93,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     if (m < p.M) {
       const int n = m / p.HWout;
       const int rem = m - n * p.HWout;
-      const int oy = rem / p.Wout;
-      const int ox = rem - oy * p.Wout;
       a_n[q] = n * p.Hin;
-      a_iy0[q] = oy * p.stride - p.pad;
-      a_ix0[q] = ox * p.stride - p.pad;
+      if (p.subpix) {  // m = (n, phase, y, x) over the SOURCE grid; output pixel (2y + a, 2x + b)
+        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+        const int y = r2 / p.Win, x = r2 - y * p.Win;
+        a_iy0[q] = y + (ph >> 1) - 1;
+        a_ix0[q] = x + (ph & 1) - 1;
+      } else {
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        a_iy0[q] = oy * p.stride - p.pad;
+        a_ix0[q] = ox * p.stride - p.pad;
+      }
     } else {
       a_n[q] = 0;
       a_iy0[q] = -(1 << 28);  // rows past M: always "out of bounds" -> zeros (address clamps to pixel 0 of image 0)
@@ -104,7 +112,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     }
   }
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.bytesw, 0x00020000);
-  const unsigned wboff = (unsigned)((n0 + srow) * p.K + skoff) * 4u;
+  // sub-pixel form: the tile lies inside one phase (host guarantees hw_src % BM == 0); each phase has its own [Cout][2][2][Cin] weights
+  const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;
+  const unsigned wboff = (unsigned)((phase_t * p.Cout + n0 + srow) * p.K + skoff) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -325,6 +335,18 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
   const bool add_bias = (p.splitk == 1) && p.bias != nullptr;
+  int* orow_tab = reinterpret_cast<int*>(smem) + 2048;  // past the statistics scratch (WM*BN*2 <= 2048 floats)
+  if (p.subpix) {  // scatter: row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
+    __syncthreads();
+    if (tid < BM) {
+      const int m = m0 + tid;
+      const int n = m / p.HWout, rem = m - n * p.HWout;
+      const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+      const int y = r2 / p.Win, x = r2 - y * p.Win;
+      orow_tab[tid] = (n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+    }
+    __syncthreads();
+  }
   const bool do_stats = p.gn_partial != nullptr;  // host guarantees splitk == 1 and HWout % BM == 0 (tile within one sample)
   float cs[TN], cq[TN];
 #pragma unroll
@@ -340,7 +362,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         const int row = rbase + (r & 3) + 8 * (r >> 2);
         const float v = acc[i][j][r] + bv;
         if (row < p.M) {
-          out[(long)row * p.Cout + col] = v;
+          const long orow = p.subpix ? orow_tab[row - m0] : row;
+          out[orow * p.Cout + col] = v;
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
@@ -542,6 +565,30 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// Sub-pixel weights of nearest-x2 + 3x3 (pad 1): phase (a, b) of the output reads source rows {y + a - 1, y + a} and columns
+// {x + b - 1, x + b}; its 2x2 kernel is the sum of the 3x3 taps that land on the same source pixel:
+//   a = 0: ty = 0 <- ky {0},    ty = 1 <- ky {1, 2};      a = 1: ty = 0 <- ky {0, 1},  ty = 1 <- ky {2}     (same for b / kx)
+// out: [4 phases][Cout][2][2][Cin]
+__global__ void pack_upconv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+  const long total = 4L * Cout * 4 * Cin;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int ci = (int)(o % Cin);
+    long t = o / Cin;
+    const int tx = (int)(t & 1); t >>= 1;
+    const int ty = (int)(t & 1); t >>= 1;
+    const int co = (int)(t % Cout);
+    const int ph = (int)(t / Cout);
+    const int a = ph >> 1, b = ph & 1;
+    const int ky0 = a == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), ky1 = a == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+    const int kx0 = b == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), kx1 = b == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * Cin + ci) * 3 + ky) * 3 + kx];
+    out[o] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ host-side planning
 struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
@@ -565,18 +612,20 @@ int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
-  MF_REQUIRE(d->upsample == 0 || d->upsample == 1, MF_EINVAL, "conv: upsample flag");
+  MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
+  MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
   MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
   MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
-  pl->Heff = d->Hin << d->upsample;
-  pl->Weff = d->Win << d->upsample;
+  const int up = d->upsample ? 1 : 0;
+  pl->Heff = d->Hin << up;
+  pl->Weff = d->Win << up;
   pl->Hout = (pl->Heff + 2 * d->pad - d->KH) / d->stride + 1;
   pl->Wout = (pl->Weff + 2 * d->pad - d->KW) / d->stride + 1;
   MF_REQUIRE(pl->Hout > 0 && pl->Wout > 0, MF_EINVAL, "conv: empty output");
   const long M = (long)d->N * pl->Hout * pl->Wout;
   MF_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), MF_EUNSUPPORTED, "conv: problem too large");
   pl->M = (int)M;
-  pl->K = d->KH * d->KW * (d->C1 + d->C2);
+  pl->K = (d->upsample == 2 ? 4 : d->KH * d->KW) * (d->C1 + d->C2);  // sub-pixel form: 2x2 taps per phase
   return MF_OK;
 }
 
@@ -588,8 +637,13 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
               (d->Cout % 32 == 0) && d->tile_hint >= 0;
   pl->splitk = 1;
   pl->nk_per_split = 0;
+  const int taps = d->upsample == 2 ? 4 : d->KH * d->KW;
+  const int hw_src = d->Hin * d->Win;
+  if (d->upsample == 2) {
+    MF_REQUIRE(pl->igemm && hw_src % 64 == 0, MF_EUNSUPPORTED, "conv: sub-pixel form needs the implicit-GEMM path and Hin*Win %% 64 == 0 (use upsample = 1)");
+  }
   if (!pl->igemm) return MF_OK;
-  int nk = d->KH * d->KW * (Cin / 32);
+  int nk = taps * (Cin / 32);
   if (d->tile_hint > 0) {
     const TileCfg* c = nullptr;
     for (const auto& k : kCfgs) if (k.id == d->tile_hint) c = &k;
@@ -604,7 +658,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     static const int variant = [] { const char* e = getenv("MF_PLANNER"); return e ? atoi(e) : 0; }();  // tuning knob (A/B runs)
     const bool c64 = d->C1 % 64 == 0 && d->C2 % 64 == 0;
     const long t128 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
-    if (d->Cout % 128 == 0 && pl->M >= 128) {
+    if (d->Cout % 128 == 0 && pl->M >= 128 && !(d->upsample == 2 && hw_src % 128)) {
       id = 8;
       if (variant == 1 && t128 < 256) id = c64 ? 24 : 4;                 // B: small tiles whenever 128x128 leaves CUs empty
       if (variant == 2 && t128 < 256 && t128 >= 128) id = c64 ? 24 : 4;  // C: ... only at the 16x16 level
@@ -613,7 +667,8 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     }
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
-  nk = d->KH * d->KW * (Cin / pl->cfg.BK);
+  nk = taps * (Cin / pl->cfg.BK);
+  MF_REQUIRE(d->upsample != 2 || hw_src % pl->cfg.BM == 0, MF_EINVAL, "conv: sub-pixel form needs Hin*Win %% tile rows == 0");
   const long tiles = (long)cdiv(pl->M, pl->cfg.BM) * (d->Cout / pl->cfg.BN);
   int sk = 1;
   if (d->splitk_hint > 0) {
@@ -666,6 +721,20 @@ int mf_conv2d_gn_parts(const MfConvDesc* d, int G) {
   return HW / pl.cfg.BM;
 }
 
+int mf_pack_upconv_weight_f32(const float* w, float* out, int Cout, int Cin, void* stream) {
+  MF_REQUIRE(w && out && Cout > 0 && Cin > 0, MF_EINVAL, "pack_upconv_weight: bad args");
+  const long total = 16L * Cout * Cin;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_upconv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
+  return check_launch("pack_upconv_weight");
+}
+
+/* 1 if `d` (with upsample = 2) can run in the sub-pixel form, else 0 (then use upsample = 1 with the regular packing) */
+int mf_conv2d_subpixel_ok(const MfConvDesc* d) {
+  Plan pl;
+  return d && d->upsample == 2 && make_plan(d, &pl) == MF_OK && pl.igemm ? 1 : 0;
+}
+
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
   Plan pl;
   if (make_plan(d, &pl) != MF_OK) return 0;
@@ -699,16 +768,19 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.x1 = x1; p.x2 = x2; p.w = w; p.bias = bias; p.y = y;
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
   p.Hout = pl.Hout; p.Wout = pl.Wout; p.Heff = pl.Heff; p.Weff = pl.Weff;
-  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.ups = d->upsample;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.ups = d->upsample == 1 ? 1 : 0;
+  p.subpix = d->upsample == 2 ? 1 : 0; p.hw_src = d->Hin * d->Win;
+  if (p.subpix) { p.KH = p.KW = 2; p.Heff = d->Hin; p.Weff = d->Win; }  // 2x2 taps on the SOURCE grid, offsets set per phase
   p.M = pl.M; p.K = pl.K; p.HWout = pl.Hout * pl.Wout;
   p.in_nchw = d->in_layout == MF_LAYOUT_NCHW; p.out_nchw = d->out_layout == MF_LAYOUT_NCHW;
-  p.cchunks = pl.igemm ? p.Cin / pl.cfg.BK : 0; p.nk = d->KH * d->KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
+  p.cchunks = pl.igemm ? p.Cin / pl.cfg.BK : 0; p.nk = p.KH * p.KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
   p.tiles_m = 0; p.tiles_n = 0; p.slab = (long)pl.M * d->Cout;
   p.bytes1 = p.bytes2 = p.bytesw = 0;
   p.gn_partial = gn_partial; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 1;
   p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
-  const double flops = 2.0 * pl.M * (double)d->Cout * pl.K;
+  // algorithmic FLOPs of the reference op (the sub-pixel form does 4/9 of the MACs of nearest-x2 + 3x3)
+  const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
 
   if (!pl.igemm && !p.out_nchw && p.Cin <= 16 && pl.K <= kSmallMaxK && d->Cout % 64 == 0 &&
@@ -741,7 +813,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.tiles_m = cdiv(pl.M, pl.cfg.BM);
   p.tiles_n = d->Cout / pl.cfg.BN;
   {
-    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = 4.0 * d->Cout * pl.K;
+    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = 4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1);
     MF_REQUIRE(b1 < 4294967040.0 && b2 < 4294967040.0 && bw < 4294967040.0, MF_EUNSUPPORTED,
                "conv: a source tensor exceeds the 4 GiB buffer-descriptor range (shard the batch)");
     p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;

@@ -59,13 +59,29 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_upconv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 -> [4 phases][Cout][2][2][Cin]: weights of the sub-pixel form of nearest-x2 + 3x3 conv."""
+    _gpu(w_oihw)
+    w = w_oihw.contiguous()
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    out = torch.empty((4, co, 2, 2, ci), dtype=torch.float32, device=w.device)
+    L.check(L.load().mf_pack_upconv_weight_f32(w.data_ptr(), out.data_ptr(), co, ci, stream()), "mf_pack_upconv_weight_f32")
+    return out
+
+
+def subpixel_ok(d: L.MfConvDesc) -> bool:
+    return bool(L.load().mf_conv2d_subpixel_ok(C.byref(d)))
+
+
 def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,
                    tile_hint=0, splitk_hint=0) -> L.MfConvDesc:
     return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, 0)
 
 
 def conv_out_hw(d: L.MfConvDesc):
-    he, we = d.Hin << d.upsample, d.Win << d.upsample
+    up = 1 if d.upsample else 0
+    he, we = d.Hin << up, d.Win << up
     return (he + 2 * d.pad - d.KH) // d.stride + 1, (we + 2 * d.pad - d.KW) // d.stride + 1
 
 

@@ -42,6 +42,8 @@ _SIGS = {
     "mf_version": (C.c_int, []),
     "mf_last_error": (C.c_char_p, []),
     "mf_pack_conv_weight_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_pack_upconv_weight_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),
+    "mf_conv2d_subpixel_ok": (_I, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),

@@ -114,6 +114,36 @@ def test_conv_direct_two_source(dev):
     assert relerr(y, want) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 0, 128, 0), (1, 16, 16, 128, 0, 128, 8), (3, 8, 16, 32, 32, 64, 4), (16, 8, 8, 512, 0, 512, 0), (2, 32, 32, 128, 0, 64, 0)])
+def test_conv_subpixel_upsample(dev, case):
+    """nearest-x2 + 3x3 conv (conv_blocks.py:123-125) in its sub-pixel form (upsample = 2) == the reference op; incl. split-K and
+    the fused GroupNorm statistics, and equal (to rounding) to the gather form (upsample = 1)."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, tile = case
+    x = _rand(f"ux{case}", (n, c1, h, w))
+    x2 = _rand(f"uy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"uw{case}", (co, c1 + c2, 3, 3), 1.0 / np.sqrt((c1 + c2) * 9))
+    b = _rand(f"ub{case}", (co,), 0.1)
+    want = _conv_ref(x, x2, wt, b, 1, 1, 1)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wsub = K.pack_upconv_weight(wt.to(dev))
+    for sk in (0, 1, 2):
+        d = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 2, tile_hint=tile, splitk_hint=sk)
+        assert K.subpixel_ok(d)
+        y = K.conv2d(xd, wsub, b.to(dev), d, x2=x2d)
+        assert y.shape == (n, 2 * h, 2 * w, co)
+        assert relerr(K.nhwc_to_nchw(y), want) < 1e-5, (case, sk)
+        parts = K.conv_gn_parts(d, 8)
+        if parts:
+            y2, partial = K.conv2d_gn(xd, wsub, b.to(dev), d, 8, parts, x2=x2d)
+            assert torch.equal(y2, y)
+            assert relerr(partial[..., 0].sum(1), want.double().reshape(n, 8, -1).sum(-1)) < 1e-4
+            assert relerr(partial[..., 1].sum(1), (want.double() ** 2).reshape(n, 8, -1).sum(-1)) < 1e-5
+    d = K.make_conv_desc(n, 5, 6, c1, c2, co, 3, 1, 1, 2)  # 30 source pixels: not a multiple of 64 -> refused, gather form is used
+    assert not K.subpixel_ok(d)
+
+
 def test_conv_smallcin_two_source(dev):
     """in_conv with self-conditioning: torch.cat([x_t, self_cond]) as two NHWC sources of 8 channels each."""
     from medfusion_amd import kernels as K
