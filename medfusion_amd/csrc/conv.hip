@@ -54,13 +54,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + within;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED, int BK, bool PP, int DBG>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   constexpr int LDK = BK + 4;  // +4 floats: conflict-free ds_read_b128 for both BK = 32 and 64
   static_assert(BK == 32 || BK == 64, "BK");
-  static_assert(!SCHED || BK == 32, "pinned schedule only for BK = 32");
-  static_assert(!PP || (NT == 512 && !SCHED), "ping-pong needs 8 waves (two per SIMD)");
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
@@ -176,46 +174,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
 
   // Pipeline (one barrier per K-chunk, at the TOP of the iteration):
   //   iteration k:  barrier | fragment reads (first 8-k slice) | LDS-store chunk k+1 (registers, loaded during
-  //                 iteration k-1) -> buf^1 | MFMAs of chunk k from buf with, interleaved between them, the global
-  //                 loads of chunk k+2 -> registers and the fragment reads of the next slices.
-  // PMC evidence (profiles/r01_pmc_conv.md): without the interleave every wave of a workgroup enters its memory
-  // phase together and the matrix pipe idles 30 % of the time; the MFMA is 64 cycles long, i.e. 16 issue slots each.
+  //                 iteration k-1) -> buf^1 | issue the global loads of chunk k+2 -> registers | MFMAs of chunk k from buf,
+  //                 fragment reads double-buffered per 8-k slice.
+  // Variants that were built, verified and measured SLOWER on MI355X (git history): a sched_barrier-pinned
+  // per-MFMA interleave of the gather, a ping-pong schedule between the two waves of each SIMD, BK = 64 for the 8-wave tile.
   // Hazards: buf^1 was last read in iteration k-1 (all waves are past this iteration's barrier); chunk k in buf was
   // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
-  // The gather of chunk k+2 is cut into PA + PB + 1 "pieces" (piece 0: advance the (tap, channel-chunk) counters and
-  // build the source descriptor; then one buffer load each) and one piece is issued after each MFMA sub-group;
-  // sched_barrier(0) fences keep the compiler from regrouping them in front of / behind the MFMA stream.
-  // (PI is a compile-time constant once the slice loops are unrolled: the array indices fold to registers.)
-#define MF_PIECE(PI, KC)                                                                                             \
-  {                                                                                                                  \
-    const int pi_ = (PI);                                                                                            \
-    if (pi_ == 0) {                                                                                                  \
-      MF_ADVANCE();                                                                                                  \
-      const int c0_ = cc * BK;                                                                                       \
-      const bool first_ = c0_ < p.C1;                                                                                \
-      g_Cs = first_ ? p.C1 : p.C2;                                                                                   \
-      g_coff = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                  \
-      g_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
-    } else if (pi_ <= PA) {                                                                                          \
-      const int q = pi_ - 1;                                                                                         \
-      const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;                                                              \
-      const bool ok = (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;                            \
-      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                                  \
-      const unsigned off = (unsigned)(((a_n[q] + sy) * p.Win + sx) * g_Cs + g_coff) * 4u;                            \
-      ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rs, ok ? off : 0xFFFFFFF0u, 0, 0));  \
-    } else if (pi_ <= PA + PB) {                                                                                     \
-      const int q = pi_ - 1 - PA;                                                                                    \
-      rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                                       \
-          rsw, wboff + (unsigned)(q * RPP * p.K + (KC) * BK) * 4u, 0, 0));                                           \
-    }                                                                                                                \
-  }
-  int g_Cs = 0, g_coff = 0;
-  __amdgpu_buffer_rsrc_t g_rs = rsw;
-  constexpr int NSEG = 2 * BK / 4;                  // MFMA sub-groups per chunk: BK/8 slices x 4 k-pairs
-  constexpr int PIECES = PA + PB + 1;
-  constexpr int PSTRIDE = NSEG / PIECES > 0 ? NSEG / PIECES : 1;  // spread the pieces over the sub-groups
-  static_assert(PIECES <= NSEG, "more gather pieces than MFMA sub-groups");
-
 #define MF_COMPUTE(DO_STORE, DO_LOAD, KC)                                                                            \
   {                                                                                                                  \
     __syncthreads();                                                                                                 \
@@ -224,9 +188,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     f32x4 fa[2][TM], fb[2][TN];                                                                                      \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
-    if ((DO_STORE) && DBG != 2) MF_LDS_STORE(buf ^ 1);                                                               \
-    if (SCHED) __builtin_amdgcn_sched_barrier(0);                                                                    \
-    if ((DO_LOAD) && !SCHED && DBG != 1) { MF_ADVANCE(); MF_GLOAD(KC); }                                                       \
+    if (DO_STORE) MF_LDS_STORE(buf ^ 1);                                                                             \
+    if (DO_LOAD) { MF_ADVANCE(); MF_GLOAD(KC); }                                                       \
     _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
       const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
       if (kk + 1 < BK / 8) {                                                                                         \
@@ -235,16 +198,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
             fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                          \
       }                                                                                                              \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);      \
-        if ((DO_LOAD) && SCHED) {                                                                                    \
-          const int seg = kk * 4 + s;                                                                                \
-          if (seg % PSTRIDE == 0 && seg / PSTRIDE < PIECES) MF_PIECE(seg / PSTRIDE, KC);                             \
-          __builtin_amdgcn_sched_barrier(0);                                                                         \
-        }                                                                                                            \
-      }                                                                                                              \
     }                                                                                                                \
     buf ^= 1;                                                                                                        \
   }
@@ -273,53 +230,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
 
   int buf = 0;
   int kc = kc_beg;
-  if (PP) {
-    // Ping-pong schedule for 8-wave workgroups (PMC: with a common barrier per chunk BOTH waves of every SIMD are in their
-    // memory phase at the same time and the matrix pipe idles ~25 %).  Waves 0-3 (one per SIMD) and their SIMD partners
-    // 4-7 alternate roles every barrier interval:
-    //   interval 2k   : A = MFMAs of chunk k          | B = LDS-store its share of chunk k+1, issue its loads of chunk k+2
-    //   interval 2k+1 : A = store k+1 / load k+2      | B = MFMAs of chunk k
-    // so one wave per SIMD is always inside its MFMA segment.  buf[(k+1)&1] last held chunk k-1, whose readers finished in
-    // intervals 2k-2 (A) and 2k-1 (B); chunk k+1 is complete after interval 2k+1, first read in interval 2k+2.
-#define MF_PP_COMPUTE()                                                                                              \
-  {                                                                                                                  \
-    const float* Ab = Aw + buf * BM * LDK;                                                                           \
-    const float* Bb = Bw + buf * BN * LDK;                                                                           \
-    f32x4 fa[2][TM], fb[2][TN];                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
-    _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
-      const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
-      if (kk + 1 < BK / 8) {                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-            fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
-            fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                          \
-      }                                                                                                              \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);      \
-    }                                                                                                                \
-  }
-#define MF_PP_MEMORY()                                                                                               \
-  {                                                                                                                  \
-    if (kc + 1 < kc_end) MF_LDS_STORE(buf ^ 1);                                                                      \
-    if (kc + 2 < kc_end) {                                                                                           \
-      MF_ADVANCE();                                                                                                  \
-      MF_GLOAD(kc + 2);                                                                                              \
-    }                                                                                                                \
-  }
-    const bool groupB = __builtin_amdgcn_readfirstlane(wave) >= 4;
-    __syncthreads();  // chunk kc_beg visible
-    for (; kc < kc_end; ++kc) {
-      if (groupB) { MF_PP_MEMORY(); } else { MF_PP_COMPUTE(); }
-      __syncthreads();
-      if (groupB) { MF_PP_COMPUTE(); } else { MF_PP_MEMORY(); }
-      __syncthreads();
-      buf ^= 1;
-    }
-  } else {
   for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
     MF_COMPUTE(true, true, kc + 2);
   }
@@ -329,7 +239,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     } else {
       MF_COMPUTE(false, false, 0);
     }
-  }
   }
 
   // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -594,9 +503,6 @@ struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
     {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32},
-    {13, 64, 128, 2, 2, 32}, {17, 128, 128, 4, 2, 32}, {18, 128, 128, 2, 4, 32},  // same tiles WITH the pinned interleave (A/B only)
-    {37, 128, 128, 4, 2, 32}, {38, 128, 128, 2, 4, 32}, {39, 128, 256, 2, 4, 32},  // ping-pong schedule
-    {48, 128, 128, 2, 4, 32}, {49, 128, 128, 2, 4, 32},  // ABLATION ONLY (wrong results): tile 8 without global loads / without LDS stores
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
@@ -655,16 +561,13 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     // ONE workgroup: half the LDS/L2 traffic of two 64x128 workgroups) is best or within 2 % of best for every shape with
     // Cout % 128 == 0; 64x64 for the 64-channel VAE level.  Split-K (below) tops the grid up to >= 512 workgroups.
     int id = 6;
-    static const int variant = [] { const char* e = getenv("MF_PLANNER"); return e ? atoi(e) : 0; }();  // tuning knob (A/B runs)
     const bool c64 = d->C1 % 64 == 0 && d->C2 % 64 == 0;
-    const long t128 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
-    if (d->Cout % 128 == 0 && pl->M >= 128 && !(d->upsample == 2 && hw_src % 128)) {
-      id = 8;
-      if (variant == 1 && t128 < 256) id = c64 ? 24 : 4;                 // B: small tiles whenever 128x128 leaves CUs empty
-      if (variant == 2 && t128 < 256 && t128 >= 128) id = c64 ? 24 : 4;  // C: ... only at the 16x16 level
+    const double gflop = 2.0 * pl->M * (double)d->Cout * pl->K * 1e-9;
+    if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) {
+      id = 8;                              // 8 waves, 128x128: best for every large 3x3 shape
     } else if (d->Cout % 64 == 0) {
-      id = (variant != 0 && c64) ? 24 : 4;
-    }
+      id = c64 ? 24 : 4;                   // 64x64 (BK = 64 when the channels allow): short-K 1x1 residual convs, stride-2 convs and
+    }                                      // other < 6 GFLOP problems are launch-cost-bound: more, smaller workgroups and less split-K
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
   nk = taps * (Cin / pl->cfg.BK);
@@ -674,8 +577,9 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   if (d->splitk_hint > 0) {
     sk = d->splitk_hint;
   } else {
-    // aim for >= 2 workgroups per CU (256 CUs), keep >= 4 chunks (128 k) per split
-    while (tiles * sk < 512 && nk / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    // aim for >= 2 workgroups per CU (256 CUs); keep >= 4 chunks per split for the 8-wave tile, >= 8 for the small tiles
+    const int min_chunks = pl->cfg.WM * pl->cfg.WN == 8 ? 4 : 8;
+    while (tiles * sk < 512 && nk / (sk * 2) >= min_chunks && sk < 16) sk *= 2;
   }
   if (sk > nk) sk = nk;
   pl->nk_per_split = cdiv(nk, sk);
@@ -683,17 +587,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool SCHED = false, int BK = 32, bool PP = false, int DBG = 0>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 int launch_igemm(const ConvP& p, hipStream_t s) {
   constexpr int LDK = BK + 4;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK, PP, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SCHED, BK, PP, DBG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -835,18 +739,10 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
       case 7: rc = launch_igemm<128, 128, 4, 2>(p, s); break;
       case 8: rc = launch_igemm<128, 128, 2, 4>(p, s); break;
       case 9: rc = launch_igemm<128, 256, 2, 4>(p, s); break;
-      case 13: rc = launch_igemm<64, 128, 2, 2, true>(p, s); break;
-      case 17: rc = launch_igemm<128, 128, 4, 2, true>(p, s); break;
-      case 18: rc = launch_igemm<128, 128, 2, 4, true>(p, s); break;
-      case 37: rc = launch_igemm<128, 128, 4, 2, false, 32, true>(p, s); break;
-      case 38: rc = launch_igemm<128, 128, 2, 4, false, 32, true>(p, s); break;
-      case 39: rc = launch_igemm<128, 256, 2, 4, false, 32, true>(p, s); break;
-      case 48: rc = launch_igemm<128, 128, 2, 4, false, 32, false, 1>(p, s); break;
-      case 49: rc = launch_igemm<128, 128, 2, 4, false, 32, false, 2>(p, s); break;
-      case 23: rc = launch_igemm<64, 128, 2, 2, false, 64>(p, s); break;
-      case 24: rc = launch_igemm<64, 64, 2, 2, false, 64>(p, s); break;
-      case 27: rc = launch_igemm<128, 128, 4, 2, false, 64>(p, s); break;
-      case 28: rc = launch_igemm<128, 128, 2, 4, false, 64>(p, s); break;
+      case 23: rc = launch_igemm<64, 128, 2, 2, 64>(p, s); break;
+      case 24: rc = launch_igemm<64, 64, 2, 2, 64>(p, s); break;
+      case 27: rc = launch_igemm<128, 128, 4, 2, 64>(p, s); break;
+      case 28: rc = launch_igemm<128, 128, 2, 4, 64>(p, s); break;
       default: set_error("conv: no tile config"); rc = MF_EINVAL;
     }
   }

@@ -64,12 +64,15 @@ def main():
     ap.add_argument("--vae-batch", type=int, default=4)
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     tot_auto = tot_best = tot_fl = 0.0
     print(f"{'shape':24s} {'M':>7s} {'N':>5s} {'K':>6s} {'GF':>7s} | {'auto ms':>8s} {'TF':>6s} | best cfg (tile,splitk) ms TF | all")
     for name, n, h, w_, c1, c2, co, k, st, ups, cnt in unet_shapes(args.batch) + vae_shapes(args.vae_batch):
+        if args.only and args.only not in name:
+            continue
         pad = 1 if k == 3 else 0
         x1 = torch.randn((n, h, w_, c1), generator=g).to(dev)
         x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
@@ -83,7 +86,7 @@ def main():
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            for tile in (4, 7, 8, 24, 37, 38, 39):
+            for tile in (1, 3, 4, 7, 8, 9, 23, 24, 27, 28):
                 bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 13: 128, 17: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256}[tile]
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
                     continue

@@ -44,7 +44,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 18, 23, 24, 27, 28, 37, 38, 39])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 23, 24, 27, 28])
 def test_conv_igemm(dev, case, tile):
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, stride, ups = case
