@@ -74,8 +74,12 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
  * parts = mf_conv2d_gn_parts(d, G); 0 means this convolution cannot emit them (use mf_gn_stats_partial_f32). */
 int mf_conv2d_gn_parts(const MfConvDesc* d, int G);
+/* gn_stats (+ gn_counter: N int32 that are ZERO on entry and zero again on exit -- allocate zeroed once, reuse): optional FUSED FINALIZE -- the producer workgroup that arrives last for a sample
+ * (agent-scope release / per-sample counter / acquire; no spinning) reduces the partial records to stats[n][g] = {mean, rstd},
+ * so no separate finalize launch is needed.  NULL, NULL: partial records only. */
 int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y, void* workspace,
-                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream);
+                     size_t workspace_bytes, double* gn_partial, float* gn_stats, int32_t* gn_counter, int G, float eps,
+                     const MfConvDesc* d, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm + Swish + residual + embedding
  * Replaces nn.GroupNorm + MONAI Swish + `out + residual` + `x += emb` at conv_blocks.py:186-191,
@@ -89,6 +93,9 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
  * by mf_conv2d_gn_f32), then ONE pass that finalises mean/rstd per workgroup and applies norm+affine+act+residual+emb. */
 int mf_gn_partial_parts(int HW);
 int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int C, int G, void* stream);
+/* the same pass with the last-arriver finalize fused in: one launch -> stats[n][g] = {mean, rstd} (counter: N int32, zero on entry / zero on exit) */
+int mf_gn_stats_fused_f32(const float* x, double* partial, float* stats, int32_t* counter, int N, int HW, int C, int G, float eps,
+                          void* stream);
 /* partial sums -> stats[n][g] = {mean, rstd} (tiny kernel; measured cheaper than finalising inside every apply workgroup) */
 int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream);
 int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, float eps, const float* gamma, const float* beta,

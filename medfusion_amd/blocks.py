@@ -59,6 +59,7 @@ class _Packed:
         return self._w
 
 
+FUSED_GN_FINALIZE = False  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 
 
@@ -74,8 +75,9 @@ class Conv(nn.Module):
         self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
 
-    def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0):
-        """gn_groups > 0: also return the partial statistics of the GroupNorm that follows -> (y, partial, parts)."""
+    def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
+                gn_eps: float = 1e-5):
+        """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2])."""
         x1, x2 = _split(x)
         if in_layout == L.LAYOUT_NCHW:
             n, c1, h, w = x1.shape
@@ -102,12 +104,19 @@ class Conv(nn.Module):
             wp, b = wp[rows], b[rows]
         if not gn_groups:
             return K.conv2d(x1, wp, b, d, x2=x2, out=out)
+        ho, wo = K.conv_out_hw(d)
         if parts > 0:    # statistics fused into the conv epilogue / split-K reducer
-            y, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2)
-            return y, partial, parts
+            # finalize: a separate tiny kernel.  The last-arriver fused finalize (FUSED_GN_FINALIZE) is bit-identical but was measured
+            # 0.4 % slower end-to-end: its agent-scope release makes every producer workgroup write back its freshly dirtied L2 lines.
+            y, stats, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2, eps=gn_eps, finalize=FUSED_GN_FINALIZE)
+            if stats is None:
+                stats = K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
+            return y, stats
         y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
+        if FUSED_GN_FINALIZE:
+            return y, K.gn_stats_fused(y, gn_groups, gn_eps)
         partial, parts = K.gn_stats_partial(y, gn_groups)
-        return y, partial, parts
+        return y, K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
 
 
 class GroupNorm(nn.Module):
@@ -158,15 +167,13 @@ class BasicBlock(nn.Module):
 
 
 def _basicblock_conv_and_stats(self, x, in_layout=L.LAYOUT_NHWC):
-    """conv (+ fused GroupNorm partial statistics) -> (y, partial, parts)"""
-    return self.conv(x, in_layout=in_layout, gn_groups=self.norm.num_groups)
+    """conv (+ fused GroupNorm statistics) -> (y, stats)"""
+    return self.conv(x, in_layout=in_layout, gn_groups=self.norm.num_groups, gn_eps=self.norm.eps)
 
 
-def _basicblock_finish(self, y_partial, residual=None, emb=None, emb_stride=0):
-    y, partial, parts = y_partial
+def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
+    y, stats = y_stats
     nm = self.norm
-    n, h, w, c = y.shape
-    stats = K.gn_finalize(partial, parts, h * w, c, nm.num_groups, nm.eps)
     return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
 
 

@@ -44,6 +44,7 @@ struct ConvP {
   int subpix, hw_src;               // sub-pixel form of nearest-x2 + 3x3: 4 phase-specific 2x2 convs on the low-res source
   double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
   int gn_groups, gn_parts, gn_cpg;
+  GnFinal gn_fin;                   // optional last-arriver finalize -> stats[n][g] = {mean, rstd}
 };
 
 // bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
@@ -307,6 +308,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
       o[0] = s;
       o[1] = q;
+    }
+    if (p.gn_fin.stats) {
+      __syncthreads();  // chs[] consumed
+      double* red = reinterpret_cast<double*>(smem);  // 2*NT doubles + flag: far below the tile buffers' size
+      gn_arrive_and_finalize(p.gn_fin, p.gn_partial, m0 / p.HWout, p.gn_groups, reinterpret_cast<volatile int*>(red + 2 * NT), red);
     }
   }
 }
@@ -646,22 +652,28 @@ size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
   return (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
 }
 
+struct GnOut { double* partial; float* stats; int32_t* counter; int G; float eps; };
 static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
-                       double* gn_partial, int G, const MfConvDesc* d, void* stream);
+                       const GnOut& gn, const MfConvDesc* d, void* stream);
 
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
                   size_t workspace_bytes, const MfConvDesc* d, void* stream) {
-  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, nullptr, 0, d, stream);
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{nullptr, nullptr, nullptr, 0, 0.f}, d, stream);
 }
 
 int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
-                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream) {
+                     size_t workspace_bytes, double* gn_partial, float* gn_stats, int32_t* gn_counter, int G, float eps, const MfConvDesc* d,
+                     void* stream) {
   MF_REQUIRE(gn_partial && mf_conv2d_gn_parts(d, G) > 0, MF_EUNSUPPORTED, "conv_gn: this convolution cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
-  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, gn_partial, G, d, stream);
+  MF_REQUIRE((gn_stats == nullptr) == (gn_counter == nullptr), MF_EINVAL, "conv_gn: gn_stats and gn_counter go together");
+  MF_REQUIRE(G <= 256, MF_EUNSUPPORTED, "conv_gn: G > 256");
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{gn_partial, gn_stats, gn_counter, G, eps}, d, stream);
 }
 
 static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
-                       double* gn_partial, int G, const MfConvDesc* d, void* stream) {
+                       const GnOut& gn, const MfConvDesc* d, void* stream) {
+  double* gn_partial = gn.partial;
+  const int G = gn.G;
   Plan pl;
   int rc = make_plan(d, &pl);
   if (rc) return rc;
@@ -683,6 +695,12 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.gn_partial = gn_partial; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 1;
   p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
+  p.gn_fin = GnFinal{};
+  const int HWo = pl.Hout * pl.Wout;
+  if (gn.stats) {  // last-arriver finalize (gn.counter: zero on entry, zero again on exit)
+    if (pl.igemm && pl.splitk == 1)
+      p.gn_fin = GnFinal{gn.stats, gn.counter, (HWo / pl.cfg.BM) * (d->Cout / pl.cfg.BN), HWo / pl.cfg.BM, (double)HWo * (d->Cout / G), gn.eps};
+  }
   // algorithmic FLOPs of the reference op (the sub-pixel form does 4/9 of the MACs of nearest-x2 + 3x3)
   const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
@@ -751,9 +769,10 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     if (gn_partial) {  // reduction + bias + GroupNorm partial statistics in one streaming pass
       const int HW = pl.Hout * pl.Wout;
       ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
-      const int slices = stats_slices(d->N, HW, d->Cout, G);
-      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(stats_chunks(HW), d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y);
+      const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
+      const GnFinal fin = gn.stats ? GnFinal{gn.stats, gn.counter, chunks * slices, chunks, (double)HW * (d->Cout / G), gn.eps} : GnFinal{};
+      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, fin);
       return check_launch("splitk_reduce_stats");
     }
     const long n4 = (long)pl.M * d->Cout / 4;

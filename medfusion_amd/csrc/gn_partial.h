@@ -25,7 +25,64 @@ inline int stats_slices(int N, int HW, int C, int G) {
 inline size_t stats_lds_bytes(int Cs) {  // Cs = channels per slice
   const int C4 = Cs / 4;
   const int lanes_per_row = C4 < kStatsThreads ? C4 : kStatsThreads;
-  return (size_t)(kStatsThreads / lanes_per_row) * Cs * 2 * sizeof(float);
+  const size_t a = (size_t)(kStatsThreads / lanes_per_row) * Cs * 2 * sizeof(float);
+  const size_t b = (size_t)(2 * kStatsThreads + 2) * sizeof(double);  // fused finalize scratch + flag
+  return a > b ? a : b;
+}
+
+// Last-arriver finalize (no spinning, placement-independent; CDNA guide §6 G16 counter form): every producer workgroup of sample n
+// drains its partial-record stores, one lane issues an agent-scope release and bumps counter[n]; the workgroup that draws
+// total-1 acquires and reduces the P x G records of the sample to stats[n][g] = {mean, rstd} in fp64.
+// `flag` is one int of the caller's dynamic LDS (a second static __shared__ object would perturb the conv pipeline's waits).
+struct GnFinal {
+  float* stats;        // [N][G][2] or nullptr (no fused finalize)
+  int* counter;        // [N]: must be ZERO on entry; the last arriver resets it, so it is zero again on exit (allocate zeroed once)
+  int total;           // producer workgroups per sample
+  int parts;           // P: partial records per sample and group
+  double count;        // elements per group
+  float eps;
+};
+
+__device__ __forceinline__ void gn_arrive_and_finalize(const GnFinal& f, const double* partial, int n, int G, volatile int* flag, double* red) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its partial-record stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(f.counter + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (prev == f.total - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*flag == 0) return;  // uniform per workgroup
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __hip_atomic_store(f.counter + n, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning: ready for the next launch
+  }
+  __syncthreads();
+  // thread = (phase, g): phases stride over the P records, then a tree over phases in `red` (>= 2*blockDim doubles of LDS)
+  const int nt = blockDim.x;
+  const int phases = G <= nt ? nt / G : 1;
+  const int g = threadIdx.x % G, ph = threadIdx.x / G;
+  for (int g0 = 0; g0 < G; g0 += nt) {  // G > blockDim only in theory
+    const int gg = g0 + g;
+    double s = 0, q = 0;
+    if (ph < phases && gg < G)
+      for (int c = ph; c < f.parts; c += phases) {
+        const double* pp = partial + (((long)n * f.parts + c) * G + gg) * 2;
+        s += pp[0]; q += pp[1];
+      }
+    red[threadIdx.x * 2] = s; red[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (ph == 0 && gg < G) {
+      for (int k = 1; k < phases; ++k) { s += red[(k * G + g) * 2]; q += red[(k * G + g) * 2 + 1]; }
+      const double mean = s / f.count;
+      double var = q / f.count - mean * mean;
+      if (var < 0) var = 0;
+      f.stats[((long)n * G + gg) * 2] = (float)mean;
+      f.stats[((long)n * G + gg) * 2 + 1] = (float)(1.0 / sqrt(var + (double)f.eps));
+    }
+    __syncthreads();
+  }
 }
 
 // grid (chunks, N).  Each block reduces its pixel range of sample n for all channels, then per group.
@@ -33,8 +90,9 @@ inline size_t stats_lds_bytes(int Cs) {  // Cs = channels per slice
 // REDUCE: the value is sum_z slabs[z] + bias (split-K reduction) and is also written to y.
 template <bool REDUCE>
 __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int HW, int C, int G,
-                                                                   int nslabs, long slab, const float* __restrict__ bias, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][C][2]
+                                                                   int nslabs, long slab, const float* __restrict__ bias, float* __restrict__ y,
+                                                                   const GnFinal fin) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][Cs][2], then (fused finalize) 2*256 doubles + flag
   const int chunks = gridDim.x, chunk = blockIdx.x, n = blockIdx.y;
   const int Cs = C / gridDim.z, c_off = blockIdx.z * Cs;  // this workgroup's channel slice
   const int C4 = Cs >> 2;
@@ -79,6 +137,11 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
     }
     double* o = partial + (((long)n * chunks + chunk) * G + (c_off / cpg + g)) * 2;
     o[0] = s; o[1] = q;
+  }
+  if (fin.stats) {
+    __syncthreads();  // the per-channel scratch in sh[] is dead: reuse it
+    double* red = reinterpret_cast<double*>(sh);
+    gn_arrive_and_finalize(fin, partial, n, G, reinterpret_cast<volatile int*>(red + 2 * kStatsThreads), red);
   }
 }
 

@@ -151,7 +151,7 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
   MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats: C=%d too wide", C);
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G, 1, 0L,
-                     (const float*)nullptr, (float*)nullptr);
+                     (const float*)nullptr, (float*)nullptr, GnFinal{});
   int rc = check_launch("gn_stats_partial");
   if (rc) return rc;
   const int NG = N * G;
@@ -181,6 +181,20 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
 
 int mf_gn_partial_parts(int HW) { return HW > 0 ? stats_chunks(HW) : 0; }
 
+int mf_gn_stats_fused_f32(const float* x, double* partial, float* stats, int32_t* counter, int N, int HW, int C, int G, float eps, void* stream) {
+  MF_REQUIRE(x && partial && stats && counter && N > 0 && HW > 0 && C > 0 && G > 0, MF_EINVAL, "gn_stats_fused: bad args");
+  MF_REQUIRE(C % 4 == 0 && C % G == 0, MF_EUNSUPPORTED, "gn_stats_fused: C=%d G=%d unsupported (need C%%4==0, C%%G==0)", C, G);
+  const int slices = stats_slices(N, HW, C, G), chunks = stats_chunks(HW);
+  const size_t lds = stats_lds_bytes(C / slices);
+  MF_REQUIRE(lds <= 64 * 1024 && G <= kStatsThreads, MF_EUNSUPPORTED, "gn_stats_fused: C=%d / G=%d too wide", C, G);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
+  const GnFinal fin{stats, counter, chunks * slices, chunks, (double)HW * (C / G), eps};
+  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
+                     (float*)nullptr, fin);
+  return check_launch("gn_stats_fused");
+}
+
 int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream) {
   MF_REQUIRE(partial && stats && parts > 0 && N > 0 && HW > 0 && G > 0 && C % G == 0, MF_EINVAL, "gn_finalize: bad args");
   hipStream_t s = (hipStream_t)stream;
@@ -199,7 +213,7 @@ int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int 
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(stats_chunks(HW), N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
-                     (float*)nullptr);
+                     (float*)nullptr, GnFinal{});
   return check_launch("gn_stats_partial");
 }
 

@@ -101,25 +101,57 @@ def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+_COUNTERS = {}
+
+
+def _gn_counter(device, n: int) -> torch.Tensor:
+    """Per-(device, stream) arrival counters of the fused GroupNorm finalize: zero-initialised ONCE, every launch leaves them zero."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _COUNTERS.get(key)
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("medfusion_amd: counter allocation during graph capture; run one eager warm-up first")
+        buf = torch.zeros(max(n, 256), dtype=torch.int32, device=device)
+        _COUNTERS[key] = buf
+    return buf
+
+
 def conv_gn_parts(d: L.MfConvDesc, G: int) -> int:
     """How many per-sample partial GroupNorm records this convolution emits itself (0: it cannot)."""
     return L.load().mf_conv2d_gn_parts(C.byref(d), G)
 
 
 def conv2d_gn(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, G: int, parts: int,
-              x2: Optional[torch.Tensor] = None):
-    """Convolution + the statistics of the GroupNorm that follows (conv epilogue or split-K reducer).  -> (y NHWC, partial)"""
+              x2: Optional[torch.Tensor] = None, eps: float = 1e-5, finalize: bool = True):
+    """Convolution + the statistics of the GroupNorm that follows (conv epilogue or split-K reducer).
+    finalize=True: the last-arriving producer workgroup also reduces them -> (y NHWC, stats [N,G,2], partial); else stats is None."""
     _gpu(x1, x2, w_packed, bias)
     lib = L.load()
     ho, wo = conv_out_hw(d)
     out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
     partial = torch.empty((d.N, parts, G, 2), dtype=torch.float64, device=x1.device)
+    stats = torch.empty((d.N, G, 2), dtype=torch.float32, device=x1.device) if finalize else None
+    counter = _gn_counter(x1.device, d.N) if finalize else None
     need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
-    rc = lib.mf_conv2d_gn_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(), G,
-                              C.byref(d), stream())
+    rc = lib.mf_conv2d_gn_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(), _ptr(stats),
+                              _ptr(counter), G, eps, C.byref(d), stream())
     L.check(rc, "mf_conv2d_gn_f32")
-    return out, partial
+    return out, stats, partial
+
+
+def gn_stats_fused(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
+    """x NHWC -> stats [N,G,2] in ONE launch (partial sums + last-arriver finalize)."""
+    _gpu(x)
+    n, h, w, c = x.shape
+    lib = L.load()
+    parts = lib.mf_gn_partial_parts(h * w)
+    partial = torch.empty((n, parts, G, 2), dtype=torch.float64, device=x.device)
+    stats = torch.empty((n, G, 2), dtype=torch.float32, device=x.device)
+    counter = _gn_counter(x.device, n)
+    L.check(lib.mf_gn_stats_fused_f32(x.data_ptr(), partial.data_ptr(), stats.data_ptr(), counter.data_ptr(), n, h * w, c, G, eps, stream()),
+            "mf_gn_stats_fused_f32")
+    return stats
 
 
 def gn_stats_partial(x: torch.Tensor, G: int):

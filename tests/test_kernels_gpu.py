@@ -136,8 +136,9 @@ def test_conv_subpixel_upsample(dev, case):
         assert relerr(K.nhwc_to_nchw(y), want) < 1e-5, (case, sk)
         parts = K.conv_gn_parts(d, 8)
         if parts:
-            y2, partial = K.conv2d_gn(xd, wsub, b.to(dev), d, 8, parts, x2=x2d)
+            y2, fstats, partial = K.conv2d_gn(xd, wsub, b.to(dev), d, 8, parts, x2=x2d)
             assert torch.equal(y2, y)
+            assert torch.equal(fstats, K.gn_finalize(partial, parts, 4 * h * w, co, 8))
             assert relerr(partial[..., 0].sum(1), want.double().reshape(n, 8, -1).sum(-1)) < 1e-4
             assert relerr(partial[..., 1].sum(1), (want.double() ** 2).reshape(n, 8, -1).sum(-1)) < 1e-5
     d = K.make_conv_desc(n, 5, 6, c1, c2, co, 3, 1, 1, 2)  # 30 source pixels: not a multiple of 64 -> refused, gather form is used
@@ -212,16 +213,19 @@ def test_conv_fused_groupnorm_statistics(dev, case):
         x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
         wp = K.pack_conv_weight(wt.to(dev))
         if parts > 0:
-            y, partial = K.conv2d_gn(xd, wp, b.to(dev), d, g, parts, x2=x2d)
+            y, fstats, partial = K.conv2d_gn(xd, wp, b.to(dev), d, g, parts, x2=x2d)
         else:
             y = K.conv2d(xd, wp, b.to(dev), d, x2=x2d)
             partial, parts = K.gn_stats_partial(y, g)
+            fstats = K.gn_stats_fused(y, g)
         ref_sum = yc.reshape(n, g, -1).sum(-1)
         assert relerr(partial[..., 0].sum(1), ref_sum) < 1e-5, (case, sk, parts)
         assert relerr(partial[..., 1].sum(1), (yc * yc).reshape(n, g, -1).sum(-1)) < 1e-5
         out = K.gn_apply_partial(y, partial, parts, gamma.to(dev), beta.to(dev), g, 1e-5, 1, K.nchw_to_nhwc(res.to(dev)))
         assert relerr(K.nhwc_to_nchw(out), want) < 1e-5, (case, sk, parts)
-        stats = K.gn_finalize(partial, parts, h * w, co, g)   # hot-path form: finalize kernel + plain apply
+        stats = K.gn_finalize(partial, parts, h * w, co, g)   # stand-alone finalize kernel ...
+        assert torch.equal(stats, fstats), (case, sk)          # ... == the last-arriver finalize fused into the producer (hot path)
+        assert torch.equal(K.gn_stats_fused(y, g), K.gn_stats(y, g))
         out2 = K.gn_apply(y, stats, gamma.to(dev), beta.to(dev), g, 1, K.nchw_to_nhwc(res.to(dev)))
         assert relerr(K.nhwc_to_nchw(out2), want) < 1e-5, (case, sk, parts)
 
