@@ -378,3 +378,20 @@ def test_cfg5_512px_shape_properties(dev, published):
     full = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False)
     one = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False, shard=(2, 4))
     assert relerr(one, full[2:3]) < 1e-5
+
+
+@torch.no_grad()
+def test_full_length_cfg2_trajectory_vs_oracle(dev, published):
+    """The whole of BASELINE.json configs[1] for ONE sample: 150 DDIM iterations (eta = 1, 300 noise draws) at latent (8,32,32) on
+    the published architecture, decoded to 256x256 -- HIP path vs the oracle on the GPU box's CPU, identical injected noise.
+    Checks the x_0 estimate every 10 iterations (error growth through the recurrence) and the final image."""
+    ora, pipe = published
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ora.set_noise_fn(S.PhiloxNoise(2024))
+    tr_o, tr_p = [], []
+    want = ora.sample(1, (8, 32, 32), steps=150, use_ddim=True, trace=tr_o)
+    got = pipe.sample(1, (8, 32, 32), steps=150, use_ddim=True, noise=oracle_noise(2024), trace=tr_p)
+    errs = [relerr(tr_p[i][0], tr_o[i][0]) for i in range(0, 150, 10)] + [relerr(tr_p[-1][0], tr_o[-1][0])]
+    print("x0 rel-err every 10 iterations:", " ".join(f"{e:.1e}" for e in errs), "| image:", f"{relerr(got, want):.1e}")
+    assert max(errs) < TOL
+    assert relerr(got, want) < TOL
