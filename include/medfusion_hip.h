@@ -57,8 +57,12 @@ typedef struct MfConvDesc {
   int32_t out_layout;      /* layout of y */
   int32_t tile_hint;       /* 0 = auto; else forces an implicit-GEMM tile config (tuning/tests) */
   int32_t splitk_hint;     /* 0 = auto; else forces split-K factor */
-  int32_t reserved;
+  int32_t precision;       /* MF_CONV_FP32 (0): v_mfma_f32_32x32x2_f32, bit-for-bit fp32 products; MF_CONV_FP32_SPLIT3 (1): each fp32
+                              operand split exactly into 3 bf16 terms, the 6 product terms of order <= 2 accumulated in fp32 on the
+                              bf16 matrix cores (dropped terms < 2^-23 |a*b|: fp32-class accuracy at 3/8 of the MFMA time).
+                              Only the implicit-GEMM path looks at it; the small/direct kernels are always plain fp32. */
 } MfConvDesc;
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],

@@ -10,6 +10,7 @@ There is no CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple, Union
 
 import torch
@@ -61,6 +62,9 @@ class _Packed:
 
 FUSED_GN_FINALIZE = False  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
+# Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MfConvDesc.precision): 0 = fp32 MFMA, 1/2 = every fp32 operand
+# split exactly into three bf16 terms and the six leading product terms accumulated in fp32 on the bf16 matrix cores.
+CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "0"))
 
 
 class Conv(nn.Module):
@@ -86,13 +90,13 @@ class Conv(nn.Module):
         c2 = 0 if x2 is None else x2.shape[-1]
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
-        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups)
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, CONV_PRECISION)
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
-            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout)
+            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout, precision=CONV_PRECISION)
             if self.upsample and SUBPIXEL_UPSAMPLE and rows is None:
-                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout)
+                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=CONV_PRECISION)
                 if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
                     d = d2
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)

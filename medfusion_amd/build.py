@@ -10,7 +10,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmedfusion_hip.so"
 SOURCES = ["api.hip", "conv.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

@@ -23,6 +23,16 @@ using namespace mf;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Timing experiments only (scripts/ablate_split.sh builds side libraries with -DMF_ABLATE=bits; results are then WRONG by design):
+// 1 no split arithmetic, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no second-step fragment reads, 32 no MFMAs,
+// 64 LDS stores of values that do not depend on the global loads (isolates the wait for the loads).
+#ifndef MF_ABLATE
+#define MF_ABLATE 0
+#endif
+constexpr int kAblate = MF_ABLATE;
 
 namespace {
 
@@ -55,11 +65,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + within;
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+// MODE 1 ("fp32 through 3 x bf16"): every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (truncation: h = top
+// 8 significant bits, m = the next 8, l = the last 8), and a*b is accumulated in fp32 on the bf16 matrix cores as the six terms
+// of order <= 2: ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh.  The dropped terms (am*bl, al*bm, al*bl) are < 2^-23 |a*b|, i.e.
+// below fp32 rounding of the product; v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so 6 of them cost 3/8.
+__device__ __forceinline__ void split2_bf16x3(const float x0, const float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);  // exact
+  const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);  // exact, <= 8 significant bits left
+  // pack the HIGH halves of two words into one: v_perm_b32 (no masking/shift needed)
+  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+  // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT read element 0 every time)
+  const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  unsigned h0, m0, l0, h1, m1, l1;
+  split2_bf16x3(x0, x1, h0, m0, l0);
+  split2_bf16x3(x2, x3, h1, m1, l1);
+  h = u32x2{h0, h1}; m = u32x2{m0, m1}; l = u32x2{l0, l1};
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
-  constexpr int LDK = BK + 4;  // +4 floats: conflict-free ds_read_b128 for both BK = 32 and 64
+  // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
+  // MODE 1: [3 pieces][32 bf16] = 48 words + 4: pitch/4 = 13 is odd, so the 16 rows of a quarter-wave b128 read hit distinct banks.
+  constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
+  constexpr bool FLUSH = MODE == 2;  // split mode: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
@@ -123,50 +160,100 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int tap = kc_beg / p.cchunks;
-  int cc = kc_beg - tap * p.cchunks;
+  // K-chunk order: channel chunk OUTER, filter tap INNER.  The KH*KW taps of one 32-channel chunk read the same 128-byte pixel
+  // segments (shifted by one pixel), so consecutive chunks hit L1/L2; with the taps outside, a whole pass over the channels
+  // (the A footprint of the 32 workgroups of an XCD, > 4 MB L2) lay between two uses of a line and every tap pass missed
+  // (rocprofv3: 50 % L2 hit rate, 7.7x the compulsory bytes fetched).  The weights stay [Cout][tap][Cin]: a chunk is still 128
+  // contiguous bytes per row.
+#ifndef MF_KORDER
+#define MF_KORDER 1
+#endif
+  constexpr bool kTapInner = MF_KORDER == 1;
+  const int taps_ = p.KH * p.KW;
+  int cc = kTapInner ? kc_beg / taps_ : kc_beg % p.cchunks;
+  int tap = kTapInner ? kc_beg - cc * taps_ : kc_beg / p.cchunks;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
-  f32x4 ra[PA], rb[PB];
+  // Two register sets: the gather of chunk k+3 is issued while chunk k is computed and consumed (split + LDS store) two
+  // iterations later.  With one set (one chunk of distance) 40 % of the split-mode kernel's time was the wait for these loads:
+  // the A tiles of the 32 workgroups of an XCD exceed its L2, so most of them come back from the MALL.
+  f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
 
 // (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
 // Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
 // supplies the zero padding (an out-of-range offset returns 0) -- no branch, no select on the data, one basic block.
-#define MF_GLOAD(KC)                                                                                         \
-  {                                                                                                          \
+// Chunks past the end of this workgroup's K range are "loaded" the same way (all offsets out of range).
+#define MF_GLOAD_SETUP(KC)                                                                                   \
+    const bool lv_ = (KC) < kc_end;                                                                          \
     const int c0_ = cc * BK;                                                                                 \
     const bool first_ = c0_ < p.C1;                                                                          \
     const int Cs_ = first_ ? p.C1 : p.C2;                                                                    \
     const int coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                   \
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
-        const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000);              \
-    _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                         \
-      const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;                                                      \
-      const bool ok = (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;                    \
-      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                          \
-      const unsigned off = (unsigned)(((a_n[q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                      \
-      ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
-    }                                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                           \
-        rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                             \
-            rsw, wboff + (unsigned)(q * RPP * p.K + (KC) * BK) * 4u, 0, 0));                                 \
-  }
-#define MF_ADVANCE()                          \
-  {                                           \
-    ++cc;                                     \
-    const int w1_ = (cc == p.cchunks) ? 1 : 0; \
-    cc = w1_ ? 0 : cc;                        \
-    kx += w1_;                                \
-    const int w2_ = (kx == p.KW) ? 1 : 0;     \
-    kx = w2_ ? 0 : kx;                        \
-    ky += w2_;                                \
-  }
-#define MF_LDS_STORE(BUF)                                                                                    \
+        const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000);
+#define MF_GLOAD_A(SET, Q)                                                                                   \
   {                                                                                                          \
-    float* a_ = As + (BUF) * BM * LDK + srow * LDK + skoff;                                                  \
-    float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + skoff;                                                  \
-    _Pragma("unroll") for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra[q];    \
-    _Pragma("unroll") for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb[q];    \
+    const int iy = a_iy0[Q] + ky, ix = a_ix0[Q] + kx;                                                        \
+    const bool ok = lv_ && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;               \
+    const int sy = iy >> p.ups, sx = ix >> p.ups;                                                            \
+    const unsigned off = (unsigned)(((a_n[Q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                        \
+    ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
+  }
+#define MF_GLOAD_B(SET, KC)                                                                                  \
+  _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                             \
+    rb##SET[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
+        rsw, lv_ ? wboff + (unsigned)(q * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0));
+#define MF_GLOAD(SET, KC)                                                                                    \
+  {                                                                                                          \
+    MF_GLOAD_SETUP(KC)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) MF_GLOAD_A(SET, q)                                        \
+    MF_GLOAD_B(SET, KC)                                                                                      \
+  }
+#define MF_ADVANCE()                            \
+  {                                             \
+    if (kTapInner) {                            \
+      ++kx;                                     \
+      const int w1_ = (kx == p.KW) ? 1 : 0;     \
+      kx = w1_ ? 0 : kx;                        \
+      ky += w1_;                                \
+      const int w2_ = (ky == p.KH) ? 1 : 0;     \
+      ky = w2_ ? 0 : ky;                        \
+      cc += w2_;                                \
+    } else {                                    \
+      ++cc;                                     \
+      const int w1_ = (cc == p.cchunks) ? 1 : 0; \
+      cc = w1_ ? 0 : cc;                        \
+      kx += w1_;                                \
+      const int w2_ = (kx == p.KW) ? 1 : 0;     \
+      kx = w2_ ? 0 : kx;                        \
+      ky += w2_;                                \
+    }                                           \
+  }
+#define MF_LDS_STORE(BUF, SET)                                                                               \
+  {                                                                                                          \
+    if constexpr (MODE == 0) {                                                                               \
+      float* a_ = As + (BUF) * BM * LDK + srow * LDK + skoff;                                                \
+      float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + skoff;                                                \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra##SET[q]; \
+      _Pragma("unroll") for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb##SET[q]; \
+    } else { /* 4 consecutive k of one row -> 4 bf16 (8 bytes) in each of the three piece planes of that row */ \
+      float* a_ = As + (BUF) * BM * LDK + srow * LDK + (skoff >> 1);                                         \
+      float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + (skoff >> 1);                                         \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                       \
+        u32x2 h_, m_, l_;                                                                                    \
+        split_bf16x3(ra##SET[q], h_, m_, l_);                                                                \
+        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = h_;                                                  \
+        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 16) = m_;                                             \
+        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 32) = l_;                                             \
+      }                                                                                                      \
+      _Pragma("unroll") for (int q = 0; q < PB; ++q) {                                                       \
+        u32x2 h_, m_, l_;                                                                                    \
+        split_bf16x3(rb##SET[q], h_, m_, l_);                                                                \
+        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK) = h_;                                                  \
+        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 16) = m_;                                             \
+        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 32) = l_;                                             \
+      }                                                                                                      \
+    }                                                                                                        \
   }
 
   const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
@@ -174,71 +261,188 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   const float* Bw = Bs + (wn * TN * 32) * LDK + frag_off;
 
   // Pipeline (one barrier per K-chunk, at the TOP of the iteration):
-  //   iteration k:  barrier | fragment reads (first 8-k slice) | LDS-store chunk k+1 (registers, loaded during
-  //                 iteration k-1) -> buf^1 | issue the global loads of chunk k+2 -> registers | MFMAs of chunk k from buf,
-  //                 fragment reads double-buffered per 8-k slice.
-  // Variants that were built, verified and measured SLOWER on MI355X (git history): a sched_barrier-pinned
-  // per-MFMA interleave of the gather, a ping-pong schedule between the two waves of each SIMD, BK = 64 for the 8-wave tile.
+  //   iteration k:  barrier | fragment reads | LDS-store chunk k+1 (register set (k+1)&1, loaded during iteration k-2) -> buf^1 |
+  //                 issue the global loads of chunk k+3 into the same set | MFMAs of chunk k from buf.
+  // Every iteration stores and loads (chunks past the end are all-out-of-range loads and a store nobody reads): one body, no tail.
+  // Variants that were built, verified and measured SLOWER on MI355X (git history): a ping-pong schedule between
+  // the two waves of each SIMD (fp32 and split mode), BK = 64 for the 8-wave tile.
   // Hazards: buf^1 was last read in iteration k-1 (all waves are past this iteration's barrier); chunk k in buf was
   // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
-#define MF_COMPUTE(DO_STORE, DO_LOAD, KC)                                                                            \
+#define MF_COMPUTE(SET, KC, DO_STORE, DO_LOAD)                                                                                        \
   {                                                                                                                  \
-    __syncthreads();                                                                                                 \
+    if (!(kAblate & 8)) __syncthreads();                                                                             \
     const float* Ab = Aw + buf * BM * LDK;                                                                           \
     const float* Bb = Bw + buf * BN * LDK;                                                                           \
-    f32x4 fa[2][TM], fb[2][TN];                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);    \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);    \
-    if (DO_STORE) MF_LDS_STORE(buf ^ 1);                                                                             \
-    if (DO_LOAD) { MF_ADVANCE(); MF_GLOAD(KC); }                                                       \
-    _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                          \
-      const int cur = kk & 1, nxt = cur ^ 1;                                                                         \
-      if (kk + 1 < BK / 8) {                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-            fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
-            fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                          \
+    if constexpr (MODE == 0) {                                                                                       \
+      f32x4 fa[2][TM], fb[2][TN];                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);  \
+      if (DO_STORE) MF_LDS_STORE(buf ^ 1, SET);                                                                      \
+      if (DO_LOAD) { MF_ADVANCE(); MF_GLOAD(SET, KC); }                                                              \
+      _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                        \
+        const int cur = kk & 1, nxt = cur ^ 1;                                                                       \
+        if (kk + 1 < BK / 8) {                                                                                       \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+              fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                        \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+              fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);    \
       }                                                                                                              \
-      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                  \
+    } else { /* two 16-deep MFMA steps per chunk; lane half hf reads the 8 consecutive k [16 s + 8 hf, +8) of each piece.   \
+                The chunk's other work (3-way split + LDS store of chunk k+1, fragment reads of the second step, gather of      \
+                chunk k+3) is cut into small units pinned BETWEEN the MFMAs (sched_barrier fences). */                          \
+      bf16x8 fa[2][TM][3], fb[2][TN][3];                                                                             \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+          fa[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16));     \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                 \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+          fb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));     \
+      float* sa_ = As + (buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                            \
+      float* sb_ = Bs + (buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                            \
+      unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
+      int coff_ = 0, Cs_ = 0;                                                                                        \
+      bool lv_ = false;                                                                                              \
+      __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
+      constexpr int NM = 12 * TM * TN, NI = PA + PB, RU = TM + TN;                                                   \
+      constexpr int UI = RU + 3 * (NI - 1);                                                                          \
+      static_assert(UI <= 2 * NM, "units per MFMA slot");                                                            \
+      { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
+        MF_ADVANCE();                                                                                                \
+        const int c0_ = cc * BK;                                                                                     \
+        const bool first_ = c0_ < p.C1;                                                                              \
+        lv_ = (KC) < kc_end;                                                                                         \
+        Cs_ = first_ ? p.C1 : p.C2;                                                                                  \
+        coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                 \
+        rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
+      }                                                                                                              \
+      MF_ITEM(0, 0, SET, KC) MF_ITEM(0, 1, SET, KC) MF_ITEM(0, 2, SET, KC)  /* covers the latency of the fragment reads */       \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      f32x16 accc[TM][TN];                                                                                           \
+      _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
+        constexpr int kCA[6] = {2, 0, 1, 1, 0, 0}, kCB[6] = {0, 2, 1, 0, 1, 0};  /* smallest terms first */         \
+        const int j_ = n % TN, i_ = (n / TN) % TM, t_ = (n / (TN * TM)) % 6, s_ = n / (TN * TM * 6);                 \
+        if (kAblate & 32) {                                                                                          \
+        } else if (FLUSH) {                                                                                          \
+          if (s_ == 0 && t_ == 0) {                                                                                  \
+            f32x16 z_;                                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.f;                                              \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], z_, 0, 0, 0); \
+          } else {                                                                                                   \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], accc[i_][j_], 0, 0, 0); \
+          }                                                                                                          \
+        } else {                                                                                                     \
+          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
+        }                                                                                                            \
+        { /* the units of slot n: u in [ceil(n UI / NM), ceil((n + 1) UI / NM)), at most two (an inner loop over u stayed    \
+             rolled for the 48-MFMA tiles and sent the fragment arrays to scratch) */                                     \
+          const int ulo_ = (n * UI + NM - 1) / NM, uhi_ = ((n + 1) * UI + NM - 1) / NM;                              \
+          if (ulo_ < uhi_) { MF_UNIT(ulo_, SET, KC) }                                                                \
+          if (ulo_ + 1 < uhi_) { MF_UNIT(ulo_ + 1, SET, KC) }                                                        \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+      }                                                                                                              \
+      if (FLUSH) {                                                                                                   \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);      \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];                            \
+      }                                                                                                              \
     }                                                                                                                \
     buf ^= 1;                                                                                                        \
   }
+// work unit U of a split-mode chunk (see MF_COMPUTE): [0, RU) second-step fragment reads of one 32-row sub-tile; then 3 units
+// per staging item (items 1..NI-1).
+#define MF_UNIT(U, SET, KC)                                                                                          \
+  {                                                                                                                  \
+    const int u = (U);                                                                                               \
+    if (u < RU) {                                                                                                    \
+      if (kAblate & 16) {                                                                                            \
+      } else if (u < TM) {                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+          fa[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
+      } else {                                                                                                       \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+          fb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
+      }                                                                                                              \
+    } else {                                                                                                         \
+      MF_ITEM(1 + (u - RU) / 3, (u - RU) % 3, SET, KC)                                                                   \
+    }                                                                                                                \
+  }
+// staging item IT of the chunk being stored (A rows 0..PA-1, then B rows), PART 0/1: split two floats each, PART 2: the LDS writes
+#define MF_ITEM(IT, PART, SET, KC)                                                                                     \
+  {                                                                                                                  \
+    const int it_ = (IT), part_ = (PART);                                                                            \
+    const bool isa_ = it_ < PA;                                                                                      \
+    const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (isa_ ? ra##SET[isa_ ? it_ : 0] : rb##SET[isa_ ? 0 : it_ - PA]); \
+    const float e0_ = v_[0], e1_ = v_[1], e2_ = v_[2], e3_ = v_[3];                                                  \
+    if (kAblate & 1) {                                                                                               \
+      if (part_ == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
+      if (part_ == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
+    } else {                                                                                                         \
+      if (part_ == 0) split2_bf16x3(e0_, e1_, h0_, m0_, l0_);                                                        \
+      if (part_ == 1) split2_bf16x3(e2_, e3_, h1_, m1_, l1_);                                                        \
+    }                                                                                                                \
+    if (part_ == 2 && !(kAblate & 2)) {                                                                              \
+      float* d_ = isa_ ? sa_ + it_ * RPP * LDK : sb_ + (it_ - PA) * RPP * LDK;                                       \
+      *reinterpret_cast<u32x2*>(d_) = u32x2{h0_, h1_};                                                               \
+      *reinterpret_cast<u32x2*>(d_ + 16) = u32x2{m0_, m1_};                                                          \
+      *reinterpret_cast<u32x2*>(d_ + 32) = u32x2{l0_, l1_};                                                          \
+    }                                                                                                                \
+    if (part_ == 2 && !(kAblate & 4)) { /* the register is free: gather the same row of the chunk this set holds next */ \
+      if (isa_) {                                                                                                    \
+        MF_GLOAD_A(SET, (isa_ ? it_ : 0))                                                                            \
+      } else {                                                                                                       \
+        const int qb_ = isa_ ? 0 : it_ - PA;                                                                         \
+        rb##SET[qb_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+            rsw, lv_ ? wboff + (unsigned)(qb_ * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0)); \
+      }                                                                                                              \
+    }                                                                                                                \
+  }
 
+#ifndef MF_PREFETCH
+#define MF_PREFETCH 1
+#endif
+  constexpr int kDist = MF_PREFETCH;  // gather distance in chunks (2 measured slower than 1: see DESIGN.md)
   if (kc_beg < kc_end) {
-    // cold start: put the loads of chunk 0 AND chunk 1 in flight before waiting for either (one HBM/TLB latency, not two)
-    MF_GLOAD(kc_beg);
-    f32x4 ra0[PA], rb0[PB];
-#pragma unroll
-    for (int q = 0; q < PA; ++q) ra0[q] = ra[q];
-#pragma unroll
-    for (int q = 0; q < PB; ++q) rb0[q] = rb[q];
-    if (kc_beg + 1 < kc_end) {
+    // cold start: chunks 0 and 1 in flight before waiting for either (one memory latency, not two)
+    MF_GLOAD(0, kc_beg);
+    MF_ADVANCE();
+    MF_GLOAD(1, kc_beg + 1);
+    MF_LDS_STORE(0, 0);
+    if (kDist == 2) {
       MF_ADVANCE();
-      MF_GLOAD(kc_beg + 1);
-    }
-    {
-      float* a_ = As + srow * LDK + skoff;
-      float* b_ = Bs + srow * LDK + skoff;
-#pragma unroll
-      for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra0[q];
-#pragma unroll
-      for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb0[q];
+      MF_GLOAD(0, kc_beg + 2);
     }
   }
 
   int buf = 0;
   int kc = kc_beg;
-  for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
-    MF_COMPUTE(true, true, kc + 2);
-  }
-  for (; kc < kc_end; ++kc) {      // last two chunks: nothing left to load, then nothing left to store
-    if (kc + 1 < kc_end) {
-      MF_COMPUTE(true, false, 0);
-    } else {
-      MF_COMPUTE(false, false, 0);
+  if constexpr (MODE == 0) {
+    for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
+      MF_COMPUTE(1, kc + 2, true, true);
+    }
+    for (; kc < kc_end; ++kc) {      // last two chunks: nothing left to load, then nothing left to store
+      if (kc + 1 < kc_end) {
+        MF_COMPUTE(1, kc + 2, true, false);
+      } else {
+        MF_COMPUTE(1, kc + 2, false, false);
+      }
+    }
+  } else if (kDist == 2) {
+    for (; kc + 1 < kc_end; kc += 2) {
+      MF_COMPUTE(1, kc + 3, true, true);
+      MF_COMPUTE(0, kc + 4, true, true);
+    }
+    if (kc < kc_end) {
+      MF_COMPUTE(1, kc + 3, true, true);
+    }
+  } else {
+    for (; kc < kc_end; ++kc) {
+      MF_COMPUTE(1, kc + 2, true, true);
     }
   }
 
@@ -508,7 +712,7 @@ __global__ void pack_upconv_weight_kernel(const float* __restrict__ w, float* __
 struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
-    {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32},
+    {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32}, {10, 256, 128, 4, 2, 32},
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
@@ -525,6 +729,7 @@ int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
   MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
+  MF_REQUIRE(d->precision >= 0 && d->precision <= 2, MF_EINVAL, "conv: precision flag %d", d->precision);
   MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
   MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
   MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
@@ -561,6 +766,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     for (const auto& k : kCfgs) if (k.id == d->tile_hint) c = &k;
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     MF_REQUIRE(d->C1 % c->BK == 0 && d->C2 % c->BK == 0, MF_EINVAL, "conv: tile_hint %d needs channel counts divisible by %d", d->tile_hint, c->BK);
+    MF_REQUIRE(d->precision == MF_CONV_FP32 || c->BK == 32, MF_EINVAL, "conv: tile_hint %d is not built for the split-bf16 mode", d->tile_hint);
     pl->cfg = *c;
   } else {
     // From scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.txt): the 8-wave 128x128 tile (2 waves per SIMD inside
@@ -569,7 +775,15 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     int id = 6;
     const bool c64 = d->C1 % 64 == 0 && d->C2 % 64 == 0;
     const double gflop = 2.0 * pl->M * (double)d->Cout * pl->K * 1e-9;
-    if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) {
+    if (d->precision != MF_CONV_FP32) {
+      // split-bf16 mode (sweep: profiles/r01_conv_sweep_split.txt): the matrix work per chunk is 3/8 of the fp32 kernel's while the
+      // staging is not smaller, so the tiles with a 64x64 per-wave footprint (128x256 / 256x128: half the LDS fragment traffic and
+      // 3/4 of the staging per MAC) win on every large shape; one workgroup per CU (split-K below tops the grid up to 256).
+      if (d->Cout % 256 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) id = 9;
+      else if (d->Cout % 128 == 0 && pl->M >= 256 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 256)) id = 10;
+      else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 3.0 && !(d->upsample == 2 && hw_src % 128)) id = 8;
+      else if (d->Cout % 64 == 0) id = 4;
+    } else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) {
       id = 8;                              // 8 waves, 128x128: best for every large 3x3 shape
     } else if (d->Cout % 64 == 0) {
       id = c64 ? 24 : 4;                   // 64x64 (BK = 64 when the channels allow): short-K 1x1 residual convs, stride-2 convs and
@@ -583,9 +797,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   if (d->splitk_hint > 0) {
     sk = d->splitk_hint;
   } else {
-    // aim for >= 2 workgroups per CU (256 CUs); keep >= 4 chunks per split for the 8-wave tile, >= 8 for the small tiles
-    const int min_chunks = pl->cfg.WM * pl->cfg.WN == 8 ? 4 : 8;
-    while (tiles * sk < 512 && nk / (sk * 2) >= min_chunks && sk < 16) sk *= 2;
+    if (d->precision != MF_CONV_FP32 && pl->cfg.BM * pl->cfg.BN >= 128 * 256) {
+      // 160 KB of LDS: one workgroup per CU -> exactly one wave of workgroups (256) when K allows
+      while (tiles * sk * 2 <= 256 && nk / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    } else {
+      // aim for >= 2 workgroups per CU (256 CUs); keep >= 4 chunks per split for the 8-wave tile, >= 8 for the small tiles
+      const int min_chunks = pl->cfg.WM * pl->cfg.WN == 8 ? 4 : 8;
+      while (tiles * sk < 512 && nk / (sk * 2) >= min_chunks && sk < 16) sk *= 2;
+    }
+    // split mode: the bf16 MFMA adds its 16 products and the accumulator with truncation; keep one accumulation chain short
+    // (<= 96 chunks of 32) so that the error stays at the fp32-MFMA kernel's level (tests/test_kernels_gpu.py, scripts/split_accuracy.py)
+    if (d->precision != MF_CONV_FP32) while (nk / sk > 96 && sk < 16) sk *= 2;
   }
   if (sk > nk) sk = nk;
   pl->nk_per_split = cdiv(nk, sk);
@@ -593,17 +815,17 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32>
+template <int BM, int BN, int WM, int WN, int BK = 32, int MODE = 0>
 int launch_igemm(const ConvP& p, hipStream_t s) {
-  constexpr int LDK = BK + 4;
+  constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -747,6 +969,29 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   }
   {
     ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes);
+    if (d->precision == 2) {
+      switch (pl.cfg.id) {
+        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 2>(p, s); break;
+        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 2>(p, s); break;
+        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 2>(p, s); break;
+        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 2>(p, s); break;
+        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 2>(p, s); break;
+        default: set_error("conv: tile config %d is not built for the split-bf16 chunk-sum mode", pl.cfg.id); rc = MF_EINVAL;
+      }
+    } else if (d->precision == MF_CONV_FP32_SPLIT3) {
+      switch (pl.cfg.id) {
+        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 1>(p, s); break;
+        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 1>(p, s); break;
+        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 1>(p, s); break;
+        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 1>(p, s); break;
+        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 1>(p, s); break;
+        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 1>(p, s); break;
+        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 1>(p, s); break;
+        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 1>(p, s); break;
+        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 1>(p, s); break;
+        default: set_error("conv: tile config %d is not built for the split-bf16 mode", pl.cfg.id); rc = MF_EINVAL;
+      }
+    } else
     switch (pl.cfg.id) {
       case 1: rc = launch_igemm<128, 128, 2, 2>(p, s); break;
       case 2: rc = launch_igemm<128, 64, 2, 2>(p, s); break;
@@ -757,6 +1002,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
       case 7: rc = launch_igemm<128, 128, 4, 2>(p, s); break;
       case 8: rc = launch_igemm<128, 128, 2, 4>(p, s); break;
       case 9: rc = launch_igemm<128, 256, 2, 4>(p, s); break;
+      case 10: rc = launch_igemm<256, 128, 4, 2>(p, s); break;
       case 23: rc = launch_igemm<64, 128, 2, 2, 64>(p, s); break;
       case 24: rc = launch_igemm<64, 64, 2, 2, 64>(p, s); break;
       case 27: rc = launch_igemm<128, 128, 4, 2, 64>(p, s); break;

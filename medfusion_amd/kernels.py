@@ -75,8 +75,8 @@ def subpixel_ok(d: L.MfConvDesc) -> bool:
 
 
 def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,
-                   tile_hint=0, splitk_hint=0) -> L.MfConvDesc:
-    return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, 0)
+                   tile_hint=0, splitk_hint=0, precision=0) -> L.MfConvDesc:
+    return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, precision)
 
 
 def conv_out_hw(d: L.MfConvDesc):

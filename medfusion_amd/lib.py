@@ -18,7 +18,7 @@ c_fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 class MfConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "N", "Hin", "Win", "C1", "C2", "Cout", "KH", "KW", "stride", "pad", "upsample", "in_layout", "out_layout",
-        "tile_hint", "splitk_hint", "reserved")]
+        "tile_hint", "splitk_hint", "precision")]
 
 
 class MfSchedStep(C.Structure):

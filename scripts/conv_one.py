@@ -8,12 +8,17 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 
 from medfusion_amd import kernels as K
+from medfusion_amd import lib as L
+import os
+if os.environ.get("MF_LIB_OVERRIDE"):  # timing experiments with side builds (scripts/ablate_split.sh)
+    L.LIB_PATH = Path(os.environ["MF_LIB_OVERRIDE"]).resolve()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="16,32,32,256,0,256,3,1,0", help="N,H,W,C1,C2,Cout,k,stride,ups")
 ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--splitk", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--precision", type=int, default=0)
 a = ap.parse_args()
 n, h, w, c1, c2, co, k, st, ups = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
@@ -22,7 +27,7 @@ x1 = torch.randn((n, h, w, c1), generator=g).to(dev)
 x2 = torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None
 wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
 b = torch.randn((co,), generator=g).to(dev)
-d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_hint=a.tile, splitk_hint=a.splitk)
+d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_hint=a.tile, splitk_hint=a.splitk, precision=a.precision)
 y = K.conv2d(x1, wt, b, d, x2=x2)
 for _ in range(5):
     K.conv2d(x1, wt, b, d, x2=x2, out=y)

@@ -10,6 +10,9 @@ import torch
 
 from medfusion_amd import kernels as K
 from medfusion_amd import lib as L
+import os
+if os.environ.get("MF_LIB_OVERRIDE"):  # timing experiments with side builds (scripts/ablate_split.sh)
+    L.LIB_PATH = Path(os.environ["MF_LIB_OVERRIDE"]).resolve()
 
 
 def unet_shapes(B):
@@ -65,6 +68,8 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms")
+    ap.add_argument("--tiles", default="", help="comma list of tile ids to sweep (default: all built for the precision)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -78,7 +83,7 @@ def main():
         x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
         wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
         b = torch.randn((co,), generator=g).to(dev)
-        d0 = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups)
+        d0 = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, precision=args.precision)
         ho, wo = K.conv_out_hw(d0)
         M, Kk = n * ho * wo, k * k * (c1 + c2)
         gf = 2.0 * M * co * Kk / 1e9
@@ -86,8 +91,12 @@ def main():
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            for tile in (1, 3, 4, 7, 8, 9, 23, 24, 27, 28):
-                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 13: 128, 17: 128, 18: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256}[tile]
+            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
+            for tile in tiles:
+                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256, 40: 128}[tile]
+                bm = {1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 23: 64, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 128, 40: 256}[tile]
+                if ups == 2 and (h * w_) % bm:
+                    continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
                     continue
                 if co % bn:
@@ -95,7 +104,7 @@ def main():
                 for sk in (1, 2, 4, 8, 16):
                     if sk > 1 and Kk // 32 // sk < 8:
                         continue
-                    d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk)
+                    d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))
             res.sort()
         best = res[0] if res else (t_auto, 0, 0)

@@ -69,6 +69,54 @@ def test_conv_igemm(dev, case, tile):
         assert relerr(y, want) < 1e-5, (case, tile, sk)  # fp32 fma chain vs fp64 reference, K up to 9216
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
+def test_conv_igemm_split_bf16x3(dev, case, tile):
+    """precision = MF_CONV_FP32_SPLIT3: fp32 operands split exactly into 3 bf16 terms, 6 product terms on the bf16 matrix cores,
+    fp32 accumulation.  Same tolerance as the fp32-MFMA kernel (error measured against the fp64 reference), and additionally
+    the error must not exceed 3x the fp32 kernel's own error + 1e-6 (it is the same class, not merely 'within tolerance')."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 6: 32, 7: 128, 8: 128, 9: 256, 10: 128, 37: 128, 38: 128, 39: 256, 40: 128}.get(tile, 32)
+    if tile and co % bn:
+        pytest.skip("tile does not divide Cout")
+    x = _rand(f"cx{case}", (n, c1, h, w))
+    x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"cb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want = _conv_ref(x, x2, wt, b, stride, pad, ups)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wp = K.pack_conv_weight(wt.to(dev))
+    d0 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups)
+    e0 = relerr(K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d0, x2=x2d)), want)
+    for sk in ([0] if tile == 0 else [0, 1, 2, 3]):
+        d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=1)
+        y = K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d, x2=x2d))
+        e = relerr(y, want)
+        assert e < 1e-5 and e < 3 * e0 + 1e-6, (case, tile, sk, e, e0)
+
+
+def test_conv_split_bf16x3_wide_dynamic_range(dev):
+    """operands spanning 12 orders of magnitude (and exact zeros): the 3-way split is exact at every exponent, so the error
+    relative to the fp64 result stays fp32-class per output element's own scale"""
+    from medfusion_amd import kernels as K
+    n, h, w, c, co = 1, 8, 8, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((n, c, h, w), generator=g) * torch.pow(10.0, torch.randint(-6, 7, (n, c, 1, 1), generator=g).float())
+    x[:, ::7] = 0.0
+    wt = torch.randn((co, c, 3, 3), generator=g) * 0.05
+    b = torch.zeros(co)
+    want = _conv_ref(x, None, wt, b, 1, 1, 0)
+    scale = F.conv2d(x.double().abs(), wt.double().abs(), None, padding=1).float()   # per-element magnitude of the summands
+    xd, wp = K.nchw_to_nhwc(x.to(dev)), K.pack_conv_weight(wt.to(dev))
+    for prec in (0, 1):
+        d = K.make_conv_desc(n, h, w, c, 0, co, 3, 1, 1, 0, precision=prec)
+        y = K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d)).cpu()
+        assert float(((y - want).abs() / scale).max()) < 2e-6, prec
+
+
 @pytest.mark.parametrize("case", [
     (2, 8, 8, 8, 32, 3, 1, "nchw", "nhwc"),    # in_conv: NCHW latent in
     (2, 8, 8, 32, 8, 1, 1, "nhwc", "nchw"),    # outc: NCHW out
