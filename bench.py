@@ -23,6 +23,7 @@ sys.path.insert(0, str(ROOT))
 import torch
 
 PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 16 * 157.3      # dense bf16 MFMA peak (= 2516.8; "~2.5 PF dense", same guide): the split-mode conv kernel runs on it
 GFLOP_PER_IMAGE_CFG2 = 7743.2     # SURVEY §8d / BASELINE.md: 150 x 51.202 (UNet) + 62.923 (VAE decode)
 WORKLOADS = {
     # name: (per-GPU batch, latent, ddim steps, use_ddim, num_classes, guidance)
@@ -93,6 +94,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the denoise iteration as a captured hipGraph (default for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2],
+                    help="arithmetic of the conv kernel (MF_CONV_*): 1 = fp32 via exact 3 x bf16 split (default), 0 = fp32 MFMA, 2 = split + chunk sums")
+    ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed step on the other conv arithmetic")
     args = ap.parse_args()
 
     import medfusion_amd as M
@@ -100,6 +104,10 @@ def main():
     from medfusion_amd import kernels as K
     import torch.distributed as dist
 
+    from medfusion_amd import blocks as BLK
+    if args.conv_precision is not None:
+        BLK.CONV_PRECISION = args.conv_precision
+    prec = BLK.CONV_PRECISION
     rank, local, world = D.init_from_env()
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -151,11 +159,30 @@ def main():
         tab = p.table()
         ms, n, fl, _ = tab["conv_igemm"]
         total_ms = sum(v[0] for v in tab.values())
-        ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 MFMA implicit-GEMM conv)", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
+        alg = fl / (ms * 1e-3) / 1e12          # algorithmic FLOPs of the reference convolutions / launch time
+        if prec == 0:
+            name, peak, executed = "conv_igemm_kernel<MODE 0> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv)", PEAK_FP32_TFLOPS, 1
+        else:   # six bf16 MFMA terms per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs
+            name, peak, executed = "conv_igemm_kernel<MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate)" % prec, PEAK_BF16_TFLOPS, 6
+        ach = alg * executed
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
+                "algorithmic_tflops": round(alg, 2), "executed_over_algorithmic": executed,
                 "share_of_gpu_time": round(ms / total_ms, 4),
                 "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])}}
+    alt = None
+    if not args.no_alt_path and rank == 0 and world == 1:
+        # the same step on the other conv arithmetic, timed the same way (1 warm-up + max(1, steps) runs), for comparison
+        BLK.CONV_PRECISION = 0 if prec else 1
+        one_step(2000)
+        fence()
+        t1 = time.perf_counter()
+        for k in range(max(1, args.steps)):
+            one_step(k)
+        fence()
+        dta = (time.perf_counter() - t1) / max(1, args.steps)
+        alt = {"conv_precision": BLK.CONV_PRECISION, "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)}
+        BLK.CONV_PRECISION = prec
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(wl["classes"])
@@ -166,15 +193,19 @@ def main():
             "metric": "images/sec at 256x256, 150 DDIM steps (DiffusionPipeline.sample incl. VAE decode)",
             "value": round(ips, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded weights of the published architecture, device Philox noise)",
+            "dtype": "f32", "conv_arithmetic": {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "fp32 operands split exactly into 3 bf16 terms, 6 product terms on the bf16 MFMA, fp32 accumulate (error vs fp64 <= the fp32-MFMA kernel's: tests/test_kernels_gpu.py)", 2: "as 1, per-chunk sums added by the VALU"}[prec],
+            "data": "synthetic (seeded weights of the published architecture, device Philox noise)",
             "config": {"workload": f"{args.workload}: {B} images/GPU, latent {wl['latent']}, {wl['steps']} {'DDIM' if wl['use_ddim'] else 'DDPM'} iterations, "
                                    f"{'uncond' if cond is None else 'cond %d-class g=%s' % (wl['classes'], wl['guidance'])}, decode to {8 * wl['latent'][1]}x{8 * wl['latent'][2]}",
                        "global_batch": n_global, "parallelism": f"dp{world} (batch rows sharded, 1 all-gather of images)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if alt:
+            out["other_conv_arithmetic"] = alt
         if gflop_img:
-            out["whole_path_tflops_per_gpu"] = round(ips / world * gflop_img / 1e3, 2)
-            out["whole_path_frac_of_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)
+            out["whole_path_algorithmic_tflops_per_gpu"] = round(ips / world * gflop_img / 1e3, 2)
+            if prec == 0:
+                out["whole_path_frac_of_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 100 /* 0.1.0 */
+#define MF_VERSION 101 /* 0.1.0 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -57,12 +57,16 @@ typedef struct MfConvDesc {
   int32_t out_layout;      /* layout of y */
   int32_t tile_hint;       /* 0 = auto; else forces an implicit-GEMM tile config (tuning/tests) */
   int32_t splitk_hint;     /* 0 = auto; else forces split-K factor */
-  int32_t precision;       /* MF_CONV_FP32 (0): v_mfma_f32_32x32x2_f32, bit-for-bit fp32 products; MF_CONV_FP32_SPLIT3 (1): each fp32
-                              operand split exactly into 3 bf16 terms, the 6 product terms of order <= 2 accumulated in fp32 on the
-                              bf16 matrix cores (dropped terms < 2^-23 |a*b|: fp32-class accuracy at 3/8 of the MFMA time).
-                              Only the implicit-GEMM path looks at it; the small/direct kernels are always plain fp32. */
+  int32_t precision;       /* arithmetic of the implicit-GEMM path (MF_CONV_*, below); the small/direct kernels are always plain fp32 */
 } MfConvDesc;
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1 };
+/* MF_CONV_FP32: v_mfma_f32_32x32x2_f32, products and sums exactly those of an fp32 fma chain.
+ * MF_CONV_FP32_SPLIT3: every fp32 operand is split EXACTLY into three bf16 terms (x = h + m + l, 8 significant bits each) and
+ *   a*b is accumulated in fp32 on the bf16 matrix cores as the six terms of order <= 2 (hh, hm, mh, mm, hl, lh); the dropped terms
+ *   are < 2^-23 |a*b|.  16x the MFMA rate / 6 terms = 3/8 of the matrix time.  Measured against fp64 its error is at or below the
+ *   fp32-MFMA kernel's on every shape of the path (the planner keeps one accumulation chain <= 96 chunks via split-K).
+ * MF_CONV_FP32_SPLIT3_CHUNKSUM: the same, with a fresh MFMA accumulator per 32-deep K chunk added to the running sum by the VALU
+ *   (round-to-nearest): 2-4x smaller error than MF_CONV_FP32, ~2 % slower than MF_CONV_FP32_SPLIT3. */
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],

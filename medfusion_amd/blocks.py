@@ -62,9 +62,11 @@ class _Packed:
 
 FUSED_GN_FINALIZE = False  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
-# Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MfConvDesc.precision): 0 = fp32 MFMA, 1/2 = every fp32 operand
-# split exactly into three bf16 terms and the six leading product terms accumulated in fp32 on the bf16 matrix cores.
-CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "0"))
+# Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*):
+#   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
+#     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
+#     per-chunk sums added by the VALU (the most accurate of the three).  Read per call: set blocks.CONV_PRECISION or the env var.
+CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
 
 
 class Conv(nn.Module):

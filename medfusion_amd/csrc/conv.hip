@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
-  constexpr bool FLUSH = MODE == 2;  // split mode: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
+  constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
@@ -969,10 +969,14 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   }
   {
     ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes);
-    if (d->precision == 2) {
+    if (d->precision == MF_CONV_FP32_SPLIT3_CHUNKSUM) {
       switch (pl.cfg.id) {
         case 1: rc = launch_igemm<128, 128, 2, 2, 32, 2>(p, s); break;
+        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 2>(p, s); break;
+        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 2>(p, s); break;
         case 4: rc = launch_igemm<64, 64, 2, 2, 32, 2>(p, s); break;
+        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 2>(p, s); break;
+        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 2>(p, s); break;
         case 8: rc = launch_igemm<128, 128, 2, 4, 32, 2>(p, s); break;
         case 9: rc = launch_igemm<128, 256, 2, 4, 32, 2>(p, s); break;
         case 10: rc = launch_igemm<256, 128, 4, 2, 32, 2>(p, s); break;
