@@ -65,14 +65,21 @@ typedef struct MfConvDesc {
  *   are < 2^-23 |a*b|.  16x the MFMA rate / 6 terms = 3/8 of the matrix time.  Measured against fp64 its error is at or below the
  *   fp32-MFMA kernel's on every shape of the path (the planner keeps one accumulation chain <= 96 chunks via split-K).
  * MF_CONV_FP32_SPLIT3_CHUNKSUM: the same, with a fresh MFMA accumulator per 32-deep K chunk added to the running sum by the VALU
- *   (round-to-nearest): 2-4x smaller error than MF_CONV_FP32, ~2 % slower than MF_CONV_FP32_SPLIT3. */
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2 };
+ *   (round-to-nearest): 2-4x smaller error than MF_CONV_FP32, ~2 % slower than MF_CONV_FP32_SPLIT3.
+ * MF_CONV_FP32_SPLIT3_W3: MF_CONV_FP32_SPLIT3 (bit-identical results) with `w_packed` pointing to the weights ALREADY split:
+ *   mf_split_conv_weight_bf16x3 turns either fp32 packing ([rows][K]) into [rows][K/8][3 pieces][8] bf16 (6 bytes per weight) once
+ *   at load time; the kernel then moves them to LDS without any arithmetic.  Implicit-GEMM path only (mf_conv2d_is_igemm). */
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],
  * each phase kernel = sum of the 3x3 taps that land on the same source pixel.  mf_conv2d_subpixel_ok: can `d` (upsample = 2) run so? */
 int mf_pack_upconv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, void* stream);
 int mf_conv2d_subpixel_ok(const MfConvDesc* d);
+/* 1 if `d` runs on the implicit-GEMM kernel (the only one that looks at `precision`), 0 for the small-Cin / direct kernels */
+int mf_conv2d_is_igemm(const MfConvDesc* d);
+/* rows = Cout (x4 for the sub-pixel packing); out: rows * K * 6 bytes */
+int mf_split_conv_weight_bf16x3(const float* w_packed, void* w_split, long rows, int K, void* stream);
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
 /* y = conv(x1 (++ x2 on channels), w) + bias.  bias may be NULL.  workspace >= mf_conv2d_workspace_bytes. */
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,

@@ -47,6 +47,7 @@ class _Packed:
     def __init__(self, subpixel: bool = False):
         self._key = None
         self._w = None
+        self._w3 = None
         self._subpixel = subpixel
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
@@ -56,8 +57,16 @@ class _Packed:
             if w.dim() == 3:  # Conv1d [O, I, 1]
                 w = w.unsqueeze(-1)
             self._w = K.pack_upconv_weight(w) if self._subpixel else K.pack_conv_weight(w)
+            self._w3 = None
             self._key = key
         return self._w
+
+    def get_split(self, weight: torch.Tensor) -> torch.Tensor:
+        """the same weights as bf16 triplets (MF_CONV_FP32_SPLIT3_W3), derived once from the fp32 packing"""
+        wp = self.get(weight)
+        if self._w3 is None:
+            self._w3 = K.split_conv_weight(wp)
+        return self._w3
 
 
 FUSED_GN_FINALIZE = False  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
@@ -67,6 +76,7 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
 #     per-chunk sums added by the VALU (the most accurate of the three).  Read per call: set blocks.CONV_PRECISION or the env var.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
+PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
 
 
 class Conv(nn.Module):
@@ -92,7 +102,7 @@ class Conv(nn.Module):
         c2 = 0 if x2 is None else x2.shape[-1]
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
-        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, CONV_PRECISION)
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, CONV_PRECISION, PRESPLIT_WEIGHTS)
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
@@ -101,10 +111,13 @@ class Conv(nn.Module):
                 d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=CONV_PRECISION)
                 if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
                     d = d2
+            if d.precision == 1 and PRESPLIT_WEIGHTS and rows is None and K.conv_is_igemm(d):
+                d.precision = 3  # MF_CONV_FP32_SPLIT3_W3
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
             self._descs[key] = ent
         d, parts = ent
-        wp = self._packed_sub.get(self.weight) if d.upsample == 2 else self._packed.get(self.weight)
+        pk = self._packed_sub if d.upsample == 2 else self._packed
+        wp = pk.get_split(self.weight) if d.precision == 3 else pk.get(self.weight)
         b = self.bias
         if rows is not None:  # output-channel slice (learned-variance head split)
             wp, b = wp[rows], b[rows]

@@ -96,12 +96,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
+  constexpr bool WS = MODE == 3;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
   constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
   constexpr int PA = BM / RPP, PB = BN / RPP;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+  constexpr int RPW = NT / 4;                 // pre-split weights: 4 threads (8 k each: 3 x 16 bytes) cover one 32-k row
+  constexpr int PW = WS ? BN / RPW : 1;
+  static_assert(!WS || BN % RPW == 0, "tile/threads mismatch (pre-split weights)");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BM][LDK]
@@ -151,6 +155,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   // sub-pixel form: the tile lies inside one phase (host guarantees hw_src % BM == 0); each phase has its own [Cout][2][2][Cin] weights
   const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;
   const unsigned wboff = (unsigned)((phase_t * p.Cout + n0 + srow) * p.K + skoff) * 4u;
+  const int wrow = tid >> 2, wo = tid & 3;
+  const unsigned wsoff = (unsigned)((phase_t * p.Cout + n0 + wrow) * p.K) * 6u + (unsigned)wo * 48u;  // 6 bytes per weight
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -174,10 +180,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   int tap = kTapInner ? kc_beg - cc * taps_ : kc_beg / p.cchunks;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
-  // Two register sets: the gather of chunk k+3 is issued while chunk k is computed and consumed (split + LDS store) two
-  // iterations later.  With one set (one chunk of distance) 40 % of the split-mode kernel's time was the wait for these loads:
-  // the A tiles of the 32 workgroups of an XCD exceed its L2, so most of them come back from the MALL.
+  // Two register sets: set 0 holds chunk 0 during the cold start only, set 1 is the steady-state prefetch register set
+  // (a gather running TWO chunks ahead through both sets was built and measured: -1...+1 %, not kept).
   f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+  u32x4 rw0[PW][3], rw1[PW][3];
 
 // (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
 // Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
@@ -199,10 +205,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     const unsigned off = (unsigned)(((a_n[Q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                        \
     ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
   }
+#define MF_GLOAD_W(SET, Q)                                                                                   \
+  _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
+    rw##SET[Q][c] = __builtin_amdgcn_raw_buffer_load_b128(                                                   \
+        rsw, lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 6u + c * 16u : 0xFFFFFFF0u, 0, 0);
+#define MF_GLOAD_B1(SET, Q)                                                                                  \
+  rb##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+      rsw, lv_ ? wboff + (unsigned)((Q) * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0));
 #define MF_GLOAD_B(SET, KC)                                                                                  \
-  _Pragma("unroll") for (int q = 0; q < PB; ++q)                                                             \
-    rb##SET[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                            \
-        rsw, lv_ ? wboff + (unsigned)(q * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0));
+  if constexpr (WS) {                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < PW; ++q) MF_GLOAD_W(SET, q)                                        \
+  } else {                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q) MF_GLOAD_B1(SET, q)                                       \
+  }
 #define MF_GLOAD(SET, KC)                                                                                    \
   {                                                                                                          \
     MF_GLOAD_SETUP(KC)                                                                                       \
@@ -246,12 +261,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 16) = m_;                                             \
         *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 32) = l_;                                             \
       }                                                                                                      \
-      _Pragma("unroll") for (int q = 0; q < PB; ++q) {                                                       \
-        u32x2 h_, m_, l_;                                                                                    \
-        split_bf16x3(rb##SET[q], h_, m_, l_);                                                                \
-        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK) = h_;                                                  \
-        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 16) = m_;                                             \
-        *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 32) = l_;                                             \
+      if constexpr (WS) {                                                                                    \
+        float* w_ = Bs + (BUF) * BN * LDK + wrow * LDK + wo * 4;                                             \
+        _Pragma("unroll") for (int q = 0; q < PW; ++q)                                                       \
+          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                      \
+            *reinterpret_cast<u32x4*>(w_ + q * RPW * LDK + c * 16) = rw##SET[q][c];                          \
+      } else {                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < PB; ++q) {                                                     \
+          u32x2 h_, m_, l_;                                                                                  \
+          split_bf16x3(rb##SET[q], h_, m_, l_);                                                              \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK) = h_;                                                \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 16) = m_;                                           \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 32) = l_;                                           \
+        }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
   }
@@ -308,8 +330,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       int coff_ = 0, Cs_ = 0;                                                                                        \
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
-      constexpr int NM = 12 * TM * TN, NI = PA + PB, RU = TM + TN;                                                   \
-      constexpr int UI = RU + 3 * (NI - 1);                                                                          \
+      float* sw_ = Bs + (buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                                  \
+      constexpr int NM = 12 * TM * TN, RU = TM + TN, UA = 3 * (PA - 1);                                              \
+      constexpr int UI = RU + UA + (WS ? PW : 3 * PB);  /* A item 0 runs before the MFMAs */                         \
       static_assert(UI <= 2 * NM, "units per MFMA slot");                                                            \
       { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
         MF_ADVANCE();                                                                                                \
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                 \
         rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
       }                                                                                                              \
-      MF_ITEM(0, 0, SET, KC) MF_ITEM(0, 1, SET, KC) MF_ITEM(0, 2, SET, KC)  /* covers the latency of the fragment reads */       \
+      MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       f32x16 accc[TM][TN];                                                                                           \
       _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
@@ -368,55 +391,57 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
           fb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
       }                                                                                                              \
+    } else if (u < RU + UA) {                                                                                        \
+      MF_ITEM_A(1 + (u - RU) / 3, (u - RU) % 3, SET)                                                                 \
+    } else if constexpr (WS) {                                                                                       \
+      MF_ITEM_W(u - RU - UA, SET)                                                                                    \
     } else {                                                                                                         \
-      MF_ITEM(1 + (u - RU) / 3, (u - RU) % 3, SET, KC)                                                                   \
+      MF_ITEM_B((u - RU - UA) / 3, (u - RU - UA) % 3, SET)                                                           \
     }                                                                                                                \
   }
-// staging item IT of the chunk being stored (A rows 0..PA-1, then B rows), PART 0/1: split two floats each, PART 2: the LDS writes
-#define MF_ITEM(IT, PART, SET, KC)                                                                                     \
-  {                                                                                                                  \
-    const int it_ = (IT), part_ = (PART);                                                                            \
-    const bool isa_ = it_ < PA;                                                                                      \
-    const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (isa_ ? ra##SET[isa_ ? it_ : 0] : rb##SET[isa_ ? 0 : it_ - PA]); \
+// staging items of the chunk being stored.  PART 0/1: split two floats each into bf16 triplets, PART 2: the three 8-byte LDS
+// writes, then the register is free: gather the same row of the chunk this register set holds next.
+#define MF_SPLIT_PARTS(V, PART, DST)                                                                                 \
+    const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (V);                                  \
     const float e0_ = v_[0], e1_ = v_[1], e2_ = v_[2], e3_ = v_[3];                                                  \
     if (kAblate & 1) {                                                                                               \
-      if (part_ == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
-      if (part_ == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
+      if ((PART) == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
+      if ((PART) == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
     } else {                                                                                                         \
-      if (part_ == 0) split2_bf16x3(e0_, e1_, h0_, m0_, l0_);                                                        \
-      if (part_ == 1) split2_bf16x3(e2_, e3_, h1_, m1_, l1_);                                                        \
+      if ((PART) == 0) split2_bf16x3(e0_, e1_, h0_, m0_, l0_);                                                       \
+      if ((PART) == 1) split2_bf16x3(e2_, e3_, h1_, m1_, l1_);                                                       \
     }                                                                                                                \
-    if (part_ == 2 && !(kAblate & 2)) {                                                                              \
-      float* d_ = isa_ ? sa_ + it_ * RPP * LDK : sb_ + (it_ - PA) * RPP * LDK;                                       \
+    if ((PART) == 2 && !(kAblate & 2)) {                                                                             \
+      float* d_ = (DST);                                                                                             \
       *reinterpret_cast<u32x2*>(d_) = u32x2{h0_, h1_};                                                               \
       *reinterpret_cast<u32x2*>(d_ + 16) = u32x2{m0_, m1_};                                                          \
       *reinterpret_cast<u32x2*>(d_ + 32) = u32x2{l0_, l1_};                                                          \
-    }                                                                                                                \
-    if (part_ == 2 && !(kAblate & 4)) { /* the register is free: gather the same row of the chunk this set holds next */ \
-      if (isa_) {                                                                                                    \
-        MF_GLOAD_A(SET, (isa_ ? it_ : 0))                                                                            \
-      } else {                                                                                                       \
-        const int qb_ = isa_ ? 0 : it_ - PA;                                                                         \
-        rb##SET[qb_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
-            rsw, lv_ ? wboff + (unsigned)(qb_ * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0)); \
-      }                                                                                                              \
-    }                                                                                                                \
+    }
+#define MF_ITEM_A(Q, PART, SET)                                                                                      \
+  {                                                                                                                  \
+    const int qa_ = (Q) < PA ? (Q) : 0;                                                                              \
+    MF_SPLIT_PARTS(ra##SET[qa_], PART, sa_ + qa_ * RPP * LDK)                                                        \
+    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_A(SET, qa_)                                                          \
+  }
+#define MF_ITEM_B(Q, PART, SET)                                                                                      \
+  {                                                                                                                  \
+    const int qb_ = (Q) < PB ? (Q) : 0;                                                                              \
+    MF_SPLIT_PARTS(rb##SET[qb_], PART, sb_ + qb_ * RPP * LDK)                                                        \
+    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_B1(SET, qb_)                                                         \
+  }
+#define MF_ITEM_W(Q, SET)                                                                                            \
+  {                                                                                                                  \
+    const int qw_ = (Q) < PW ? (Q) : 0;                                                                              \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(sw_ + qw_ * RPW * LDK + c * 16) = rw##SET[qw_][c]; \
+    MF_GLOAD_W(SET, qw_)                                                                                             \
   }
 
-#ifndef MF_PREFETCH
-#define MF_PREFETCH 1
-#endif
-  constexpr int kDist = MF_PREFETCH;  // gather distance in chunks (2 measured slower than 1: see DESIGN.md)
   if (kc_beg < kc_end) {
     // cold start: chunks 0 and 1 in flight before waiting for either (one memory latency, not two)
     MF_GLOAD(0, kc_beg);
     MF_ADVANCE();
     MF_GLOAD(1, kc_beg + 1);
     MF_LDS_STORE(0, 0);
-    if (kDist == 2) {
-      MF_ADVANCE();
-      MF_GLOAD(0, kc_beg + 2);
-    }
   }
 
   int buf = 0;
@@ -432,15 +457,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         MF_COMPUTE(1, kc + 2, false, false);
       }
     }
-  } else if (kDist == 2) {
-    for (; kc + 1 < kc_end; kc += 2) {
-      MF_COMPUTE(1, kc + 3, true, true);
-      MF_COMPUTE(0, kc + 4, true, true);
-    }
-    if (kc < kc_end) {
-      MF_COMPUTE(1, kc + 3, true, true);
-    }
   } else {
+    // split modes: ONE body -- every iteration stores and gathers; chunks past the end of this workgroup's K range are
+    // all-out-of-range loads (zeros, no traffic) and a store into the buffer nobody reads any more
     for (; kc < kc_end; ++kc) {
       MF_COMPUTE(1, kc + 2, true, true);
     }
@@ -708,6 +727,20 @@ __global__ void pack_upconv_weight_kernel(const float* __restrict__ w, float* __
   }
 }
 
+// [rows][K] fp32 (either packing) -> [rows][K/8][3 pieces][8] bf16: the exact 3-way split of MODE 1, done once at load time
+__global__ void split_weight_kernel(const float* __restrict__ w, u32x4* __restrict__ out, long octets) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < octets; o += stride) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(w + o * 8), v1 = *reinterpret_cast<const f32x4*>(w + o * 8 + 4);
+    u32x2 h0, m0, l0, h1, m1, l1;
+    split_bf16x3(v0, h0, m0, l0);
+    split_bf16x3(v1, h1, m1, l1);
+    out[o * 3 + 0] = u32x4{h0.x, h0.y, h1.x, h1.y};
+    out[o * 3 + 1] = u32x4{m0.x, m0.y, m1.x, m1.y};
+    out[o * 3 + 2] = u32x4{l0.x, l0.y, l1.x, l1.y};
+  }
+}
+
 // ------------------------------------------------------------------ host-side planning
 struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
@@ -729,7 +762,7 @@ int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
   MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
-  MF_REQUIRE(d->precision >= 0 && d->precision <= 2, MF_EINVAL, "conv: precision flag %d", d->precision);
+  MF_REQUIRE(d->precision >= 0 && d->precision <= 3, MF_EINVAL, "conv: precision flag %d", d->precision);
   MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
   MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
   MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
@@ -861,6 +894,20 @@ int mf_pack_upconv_weight_f32(const float* w, float* out, int Cout, int Cin, voi
   return check_launch("pack_upconv_weight");
 }
 
+int mf_conv2d_is_igemm(const MfConvDesc* d) {
+  Plan pl;
+  return d && make_plan(d, &pl) == MF_OK && pl.igemm ? 1 : 0;
+}
+
+int mf_split_conv_weight_bf16x3(const float* w_packed, void* out, long rows, int K, void* stream) {
+  MF_REQUIRE(w_packed && out && rows > 0 && K > 0 && K % 8 == 0, MF_EINVAL, "split_conv_weight: bad args (K %% 8 == 0)");
+  const long octets = rows * (K / 8);
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 10.0 * rows * K);
+  const int blocks = (int)((octets + 255) / 256 > 4096 ? 4096 : (octets + 255) / 256);
+  hipLaunchKernelGGL(split_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x4*>(out), octets);
+  return check_launch("split_conv_weight");
+}
+
 /* 1 if `d` (with upsample = 2) can run in the sub-pixel form, else 0 (then use upsample = 1 with the regular packing) */
 int mf_conv2d_subpixel_ok(const MfConvDesc* d) {
   Plan pl;
@@ -900,6 +947,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   int rc = make_plan(d, &pl);
   if (rc) return rc;
   MF_REQUIRE(x1 && w && y, MF_EINVAL, "conv: null pointer");
+  MF_REQUIRE(d->precision != MF_CONV_FP32_SPLIT3_W3 || pl.igemm, MF_EINVAL,
+             "conv: MF_CONV_FP32_SPLIT3_W3 (pre-split weights) exists on the implicit-GEMM path only (ask mf_conv2d_is_igemm)");
   MF_REQUIRE(d->C2 == 0 || x2 != nullptr, MF_EINVAL, "conv: C2 > 0 but x2 is null");
   hipStream_t s = (hipStream_t)stream;
   ConvP p;
@@ -957,7 +1006,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.tiles_m = cdiv(pl.M, pl.cfg.BM);
   p.tiles_n = d->Cout / pl.cfg.BN;
   {
-    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = 4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1);
+    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = (d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : 4.0) * d->Cout * pl.K * (p.subpix ? 4 : 1);
     MF_REQUIRE(b1 < 4294967040.0 && b2 < 4294967040.0 && bw < 4294967040.0, MF_EUNSUPPORTED,
                "conv: a source tensor exceeds the 4 GiB buffer-descriptor range (shard the batch)");
     p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;
@@ -981,6 +1030,19 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
         case 9: rc = launch_igemm<128, 256, 2, 4, 32, 2>(p, s); break;
         case 10: rc = launch_igemm<256, 128, 4, 2, 32, 2>(p, s); break;
         default: set_error("conv: tile config %d is not built for the split-bf16 chunk-sum mode", pl.cfg.id); rc = MF_EINVAL;
+      }
+    } else if (d->precision == MF_CONV_FP32_SPLIT3_W3) {
+      switch (pl.cfg.id) {
+        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 3>(p, s); break;
+        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 3>(p, s); break;
+        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 3>(p, s); break;
+        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 3>(p, s); break;
+        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 3>(p, s); break;
+        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 3>(p, s); break;
+        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 3>(p, s); break;
+        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 3>(p, s); break;
+        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 3>(p, s); break;
+        default: set_error("conv: tile config %d is not built for the split-bf16 mode", pl.cfg.id); rc = MF_EINVAL;
       }
     } else if (d->precision == MF_CONV_FP32_SPLIT3) {
       switch (pl.cfg.id) {

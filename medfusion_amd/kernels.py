@@ -19,7 +19,7 @@ def _gpu(*ts):
             continue
         if not t.is_cuda:
             raise RuntimeError("medfusion_amd: tensors must live on a ROCm device -- the product path has no CPU fallback")
-        if t.dtype not in (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8):
+        if t.dtype not in (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8, torch.int16):
             raise RuntimeError(f"medfusion_amd: unsupported dtype {t.dtype}")
 
 
@@ -72,6 +72,22 @@ def pack_upconv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
 
 def subpixel_ok(d: L.MfConvDesc) -> bool:
     return bool(L.load().mf_conv2d_subpixel_ok(C.byref(d)))
+
+
+def conv_is_igemm(d: L.MfConvDesc) -> bool:
+    return bool(L.load().mf_conv2d_is_igemm(C.byref(d)))
+
+
+def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
+    """packed fp32 weights (either packing; rows = all leading dims but the K = kh*kw*cin of the last three) -> the bf16-triplet
+    form of MF_CONV_FP32_SPLIT3_W3: [rows][K/8][3][8] bf16 as an opaque int16 tensor [rows, 3K]."""
+    _gpu(w_packed)
+    w = w_packed.contiguous()
+    k = w.shape[-1] * w.shape[-2] * w.shape[-3]
+    rows = w.numel() // k
+    out = torch.empty((rows, 3 * k), dtype=torch.int16, device=w.device)
+    L.check(L.load().mf_split_conv_weight_bf16x3(w.data_ptr(), out.data_ptr(), rows, k, stream()), "mf_split_conv_weight_bf16x3")
+    return out
 
 
 def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,

@@ -44,6 +44,8 @@ _SIGS = {
     "mf_pack_conv_weight_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_pack_upconv_weight_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),
     "mf_conv2d_subpixel_ok": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_is_igemm": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_split_conv_weight_bf16x3": (_I, [c_fp, c_fp, C.c_long, _I, c_fp]),
     "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),

@@ -104,6 +104,31 @@ def test_conv_igemm_split_bf16x3(dev, case, tile):
                 assert e < 3 * e0 + 1e-6, (case, tile, sk, prec, e, e0)
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
+def test_conv_presplit_weights_bit_identical(dev, case, tile):
+    """MF_CONV_FP32_SPLIT3_W3 (weights split into bf16 triplets once, mf_split_conv_weight_bf16x3) == MF_CONV_FP32_SPLIT3 bit for bit"""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 6: 32, 7: 128, 8: 128, 9: 256, 10: 128}.get(tile, 32)
+    if tile and co % bn:
+        pytest.skip("tile does not divide Cout")
+    x = _rand(f"cx{case}", (n, c1, h, w))
+    x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"cb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wp = K.pack_conv_weight(wt.to(dev))
+    w3 = K.split_conv_weight(wp)
+    for sk in ([0] if tile == 0 else [0, 1, 3]):
+        d1 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=1)
+        d3 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=3)
+        assert K.conv_is_igemm(d3)
+        assert torch.equal(K.conv2d(xd, wp, b.to(dev), d1, x2=x2d), K.conv2d(xd, w3, b.to(dev), d3, x2=x2d)), (case, tile, sk)
+
+
 def test_conv_split_bf16x3_wide_dynamic_range(dev):
     """operands spanning 12 orders of magnitude (and exact zeros): the 3-way split is exact at every exponent, so the error
     relative to the fp64 result stays fp32-class per output element's own scale"""
