@@ -830,8 +830,8 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   if (d->splitk_hint > 0) {
     sk = d->splitk_hint;
   } else {
-    if (d->precision != MF_CONV_FP32 && pl->cfg.BM * pl->cfg.BN >= 128 * 256) {
-      // 160 KB of LDS: one workgroup per CU -> exactly one wave of workgroups (256) when K allows
+    if (d->precision != MF_CONV_FP32 && pl->cfg.BM * pl->cfg.BN >= 128 * 128) {
+      // >= 106 KB of LDS per workgroup in the split modes: one workgroup per CU -> at most one wave of workgroups (256)
       while (tiles * sk * 2 <= 256 && nk / (sk * 2) >= 4 && sk < 16) sk *= 2;
     } else {
       // aim for >= 2 workgroups per CU (256 CUs); keep >= 4 chunks per split for the 8-wave tile, >= 8 for the small tiles

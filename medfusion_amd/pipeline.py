@@ -62,6 +62,7 @@ class DiffusionPipeline(nn.Module):
         self.estimate_variance = estimate_variance
         self.clip_x0 = clip_x0
         self.batch_cfg = True  # classifier-free guidance as one 2B-row UNet call (same arithmetic per row)
+        self.hoist_embeddings = True  # denoise(): time/label/local embeddings of all iterations evaluated once, before the loop
         self.use_ema = use_ema
         if use_ema:
             self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
@@ -80,10 +81,12 @@ class DiffusionPipeline(nn.Module):
     def _estimator(self):
         return self.ema_model.averaged_model if self.use_ema else self.noise_estimator
 
-    def _predict(self, x_t, t, condition, self_cond, guidance_scale, un_cond):
-        """UNet call(s) of forward :240-253.  Returns (pred, pred_uncond|None, pred_var|None)."""
+    def _predict(self, x_t, t, condition, self_cond, guidance_scale, un_cond, emb=None):
+        """UNet call(s) of forward :240-253.  Returns (pred, pred_uncond|None, pred_var|None).
+        emb = (table, i, cols_cond, cols_uncond): the loop's precomputed embeddings (UNet.precompute_embeddings), or None."""
         est = self._estimator()
         cfg = (condition is not None) and (guidance_scale != 1.0)
+        ec = (lambda cols: None) if emb is None else (lambda cols: est.step_embeddings(emb[0], emb[1], cols))
         if cfg:
             if self.estimate_variance:
                 raise RuntimeError("estimate_variance with guidance_scale != 1 raises in the reference too "
@@ -91,16 +94,16 @@ class DiffusionPipeline(nn.Module):
             if self.batch_cfg and not self.use_self_conditioning:
                 # both passes of diffusion_pipeline.py:242-243 as ONE UNet call over 2B rows (rows are independent):
                 # rows [0,B) = un-guided (condition = un_cond, possibly None), rows [B,2B) = guided.
-                pred2 = est.forward_cfg_pair(x_t, t, condition, un_cond)
+                pred2 = est.forward_cfg_pair(x_t, t, condition, un_cond, emb_cache=None if emb is None else ec(torch.cat([emb[3], emb[2]])))
                 B = x_t.shape[0]
                 return pred2[B:], pred2[:B], None
-            pred_uncond, _ = est(x_t, t, condition=un_cond, self_cond=self_cond)  # un-guided pass FIRST (Q6)
-            pred_cond, _ = est(x_t, t, condition=condition, self_cond=self_cond)
+            pred_uncond, _ = est(x_t, t, condition=un_cond, self_cond=self_cond, emb_cache=None if emb is None else ec(emb[3]))  # un-guided pass FIRST (Q6)
+            pred_cond, _ = est(x_t, t, condition=condition, self_cond=self_cond, emb_cache=None if emb is None else ec(emb[2]))
             return pred_cond, pred_uncond, None
         if self.estimate_variance:
-            pred, pred_var = est.forward_split(x_t, t, condition=condition, self_cond=self_cond)
+            pred, pred_var = est.forward_split(x_t, t, condition=condition, self_cond=self_cond, emb_cache=None if emb is None else ec(emb[2]))
             return pred, None, pred_var
-        pred, _ = est(x_t, t, condition=condition, self_cond=self_cond)
+        pred, _ = est(x_t, t, condition=condition, self_cond=self_cond, emb_cache=None if emb is None else ec(emb[2]))
         return pred, None, None
 
     @torch.no_grad()
@@ -180,8 +183,16 @@ class DiffusionPipeline(nn.Module):
             n_ddim = torch.empty_like(x_t)
             x0 = torch.empty_like(x_t)
             self_cond = None
+            est = self._estimator()
+            emb_tab = None
+            if self.hoist_embeddings and hasattr(est, "can_precompute_embeddings") and est.can_precompute_embeddings():
+                # all timesteps are known: the embedding path leaves the loop (UNet.precompute_embeddings; bit-identical)
+                has_c = est.cond_embedder is not None
+                emb_tab = (est.precompute_embeddings(t_all[:, 0].contiguous()),
+                           est.embedding_columns(condition if has_c else None, B, dev), est.embedding_columns(un_cond if has_c else None, B, dev))
             for i in range(len(rev)):
-                pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond)
+                pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond,
+                                                            emb=None if emb_tab is None else (emb_tab[0], i, emb_tab[1], emb_tab[2]))
                 noise.draw(tuple(x_t.shape), out=n_post)          # gaussian_scheduler.py:99 -- drawn on every iteration (Q3)
                 ddim = recs[i].mode == 1
                 if ddim:

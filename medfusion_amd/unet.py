@@ -163,21 +163,25 @@ class UNet(nn.Module):
             self._emb_cache_key = key
         return self._emb_w, self._emb_b
 
-    def embed(self, t, condition, emb_override=None):
-        """Global embedding [B,E] and the lookup giving every module its embedding (unet2.py:229-241)."""
-        time_emb = None if t is None else self.time_embedder(t)
-        if emb_override is not None:
-            emb = emb_override
-        elif condition is None or self.cond_embedder is None:
-            emb = time_emb
-        elif time_emb is None:
-            emb = self.cond_embedder(condition)
-        else:  # save_add(time_emb, cond_emb): the lookup accumulates into the time embedding
-            emb = K.embedding_add(self.cond_embedder.embedding.weight, condition, time_emb)
-        if emb is None or not self._emb_blocks:
-            return emb, (lambda m: emb if isinstance(m, Attention) else None)
-        w, b = self._packed_local_embedders()
-        local_all = K.linear(emb, w, b, act_in=True)  # [B, sum Cout]
+    def embed(self, t, condition, emb_override=None, emb_cache=None):
+        """Global embedding [B,E] and the lookup giving every module its embedding (unet2.py:229-241).
+        emb_cache = (emb [B,E], local_all [B, sum Cout]) from `step_embeddings`: nothing is computed here."""
+        if emb_cache is not None:
+            emb, local_all = emb_cache
+        else:
+            time_emb = None if t is None else self.time_embedder(t)
+            if emb_override is not None:
+                emb = emb_override
+            elif condition is None or self.cond_embedder is None:
+                emb = time_emb
+            elif time_emb is None:
+                emb = self.cond_embedder(condition)
+            else:  # save_add(time_emb, cond_emb): the lookup accumulates into the time embedding
+                emb = K.embedding_add(self.cond_embedder.embedding.weight, condition, time_emb)
+            if emb is None or not self._emb_blocks:
+                return emb, (lambda m: emb if isinstance(m, Attention) else None)
+            w, b = self._packed_local_embedders()
+            local_all = K.linear(emb, w, b, act_in=True)  # [B, sum Cout]
 
         def lookup(m):
             if isinstance(m, Attention):
@@ -187,12 +191,53 @@ class UNet(nn.Module):
 
         return emb, lookup
 
+    # The sampling loop knows all of its timesteps before it starts, every row of a step shares the timestep, and a row's
+    # embedding depends on (timestep, class) only.  So the whole embedding path of unet2.py:229-241 + the local embedders of
+    # conv_blocks.py:340-353 -- sinusoid, time MLP, label lookup + save_add, 17 Linear(Swish(.)) -- is evaluated ONCE per sample()
+    # for the distinct (step, class) pairs and gathered per step.  Same kernels on the same values row by row (every kernel on this
+    # path treats rows independently), so the result is bit-identical to evaluating it inside the loop (tests: hipgraph == eager).
+    def can_precompute_embeddings(self) -> bool:
+        return (self.time_embedder is not None and bool(self._emb_blocks)
+                and (self.cond_embedder is None or isinstance(self.cond_embedder, LabelEmbedder)))
+
     @torch.no_grad()
-    def forward_cfg_pair(self, x_t, t, condition, un_cond):
+    def precompute_embeddings(self, t_steps: torch.Tensor):
+        """t_steps [S] (the loop's timesteps in loop order) -> table: column 0 = no condition, column 1 + c = class c."""
+        S = t_steps.shape[0]
+        time_emb = self.time_embedder(t_steps.to(torch.float32).contiguous())          # [S, E]
+        cols = [time_emb]
+        if self.cond_embedder is not None:
+            tab = self.cond_embedder.embedding.weight
+            for c in range(tab.shape[0]):
+                lab = torch.full((S,), c, dtype=torch.long, device=t_steps.device)
+                cols.append(K.embedding_add(tab, lab, time_emb.clone()))
+        emb = torch.stack(cols, dim=1).contiguous()                                     # [S, NCOL, E]  (plumbing)
+        w, b = self._packed_local_embedders()
+        local = K.linear(emb.view(S * len(cols), -1), w, b, act_in=True).view(S, len(cols), -1)
+        return {"emb": emb, "local": local, "need_emb": any(isinstance(m, Attention) for m in self.modules())}
+
+    @staticmethod
+    def embedding_columns(condition, B, device):
+        """row -> column of the precomputed table: 0 without a condition, 1 + label with one"""
+        if condition is None:
+            return torch.zeros((B,), dtype=torch.long, device=device)
+        return condition.to(device=device, dtype=torch.long).reshape(-1) + 1
+
+    @staticmethod
+    def step_embeddings(table, i: int, cols: torch.Tensor):
+        """(emb [B,E] | None, local_all [B, sum Cout]) of loop iteration i for rows with table columns `cols` (a gather: plumbing)"""
+        emb = table["emb"][i].index_select(0, cols) if table["need_emb"] else None
+        return emb, table["local"][i].index_select(0, cols)
+
+    @torch.no_grad()
+    def forward_cfg_pair(self, x_t, t, condition, un_cond, emb_cache=None):
         """Classifier-free-guidance pair in one pass: returns y [2B,...] with rows [0,B) = forward(x_t, t, un_cond) and
         rows [B,2B) = forward(x_t, t, condition).  Per-row arithmetic is the same as two separate calls."""
         B = x_t.shape[0]
         x2 = torch.cat([x_t, x_t], dim=0)            # plumbing: 2 x 8192*B floats
+        if emb_cache is not None:
+            h, _ = self.features(x2, None, None, None, emb_cache=emb_cache)
+            return self.outc(h)
         t2 = torch.cat([t, t], dim=0)
         time_emb = self.time_embedder(t2)              # [2B, E]
         if self.cond_embedder is not None:
@@ -205,12 +250,12 @@ class UNet(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def features(self, x_t, t=None, condition=None, self_cond=None, emb_override=None):
+    def features(self, x_t, t=None, condition=None, self_cond=None, emb_override=None, emb_cache=None):
         """Everything of unet2.py:222-264 up to (not including) the 1x1 out convolution: (h NHWC, y_ver)."""
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.UNet runs on a ROCm device only (no CPU fallback)")
         x_t = x_t.contiguous()
-        _, lookup = self.embed(t, condition, emb_override)
+        _, lookup = self.embed(t, condition, emb_override, emb_cache)
         if self.use_self_conditioning:
             # SURVEY Q11: reference concatenates zeros if self_cond is None else x_t ITSELF (unet2.py:245)
             a = K.nchw_to_nhwc(x_t)
@@ -232,17 +277,17 @@ class UNet(nn.Module):
         return h, y_ver[::-1]
 
     @torch.no_grad()
-    def forward(self, x_t, t=None, condition=None, self_cond=None):
+    def forward(self, x_t, t=None, condition=None, self_cond=None, emb_cache=None):
         """x_t [B,C,H,W] NCHW on the GPU; t [B] (long or float); condition [B] long | None.
-        Returns (y NCHW, y_ver list) like unet2.py:222-269."""
-        h, y_ver = self.features(x_t, t, condition, self_cond)
+        Returns (y NCHW, y_ver list) like unet2.py:222-269.  emb_cache: see `step_embeddings` (sampling loop only)."""
+        h, y_ver = self.features(x_t, t, condition, self_cond, emb_cache=emb_cache)
         return self.outc(h), y_ver
 
     @torch.no_grad()
-    def forward_split(self, x_t, t=None, condition=None, self_cond=None):
+    def forward_split(self, x_t, t=None, condition=None, self_cond=None, emb_cache=None):
         """estimate_variance=True: (pred, pred_var) == y.chunk(2, dim=1) of diffusion_pipeline.py:252 as two
         contiguous tensors (the two halves of `outc` run as two 1x1 convolutions over the same features)."""
         assert self.estimate_variance
-        h, _ = self.features(x_t, t, condition, self_cond)
+        h, _ = self.features(x_t, t, condition, self_cond, emb_cache=emb_cache)
         c = self.out_ch
         return self.outc(h, rows=slice(0, c)), self.outc(h, rows=slice(c, 2 * c))

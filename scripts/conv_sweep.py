@@ -49,7 +49,20 @@ def vae_shapes(B):
     return S
 
 
+_W3 = {}
+
+
+def _split_cache(w):
+    k = w.data_ptr()
+    if k not in _W3:
+        _W3.clear()
+        _W3[k] = K.split_conv_weight(w)
+    return _W3[k]
+
+
 def time_conv(x1, x2, w, b, d, reps):
+    if d.precision == 3:
+        w = _split_cache(w)
     y = K.conv2d(x1, w, b, d, x2=x2)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -68,7 +81,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
-    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms, 2: + chunk sums, 3: 1 with pre-split weights")
     ap.add_argument("--tiles", default="", help="comma list of tile ids to sweep (default: all built for the precision)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
