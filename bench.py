@@ -163,7 +163,9 @@ def main():
         if prec == 0:
             name, peak, executed = "conv_igemm_kernel<MODE 0> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv)", PEAK_FP32_TFLOPS, 1
         else:   # six bf16 MFMA terms per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs
-            name, peak, executed = "conv_igemm_kernel<MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate)" % prec, PEAK_BF16_TFLOPS, 6
+            mode = 3 if (prec == 1 and BLK.PRESPLIT_WEIGHTS) else prec
+            name, peak, executed = "conv_igemm_kernel<..., MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate%s)" % (
+                mode, "; weights pre-split at load" if mode == 3 else ""), PEAK_BF16_TFLOPS, 6
         ach = alg * executed
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": int(n), "avg_launch_ms": round(ms / n, 5),

@@ -69,13 +69,14 @@ class _Packed:
         return self._w3
 
 
-FUSED_GN_FINALIZE = False  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
+FUSED_GN_FINALIZE = bool(int(os.environ.get("MEDFUSION_FUSED_GN_FINALIZE", "0")))  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*):
 #   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
 #     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
 #     per-chunk sums added by the VALU (the most accurate of the three).  Read per call: set blocks.CONV_PRECISION or the env var.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
+APPLY_FROM_PARTIALS = bool(int(os.environ.get("MEDFUSION_APPLY_FROM_PARTIALS", "0")))  # GroupNorm finalize inside the apply pass (A/B switch)
 PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
 
 
@@ -127,14 +128,16 @@ class Conv(nn.Module):
         if parts > 0:    # statistics fused into the conv epilogue / split-K reducer
             # finalize: a separate tiny kernel.  The last-arriver fused finalize (FUSED_GN_FINALIZE) is bit-identical but was measured
             # 0.4 % slower end-to-end: its agent-scope release makes every producer workgroup write back its freshly dirtied L2 lines.
-            y, stats, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2, eps=gn_eps, finalize=FUSED_GN_FINALIZE)
+            y, stats, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2, eps=gn_eps, finalize=FUSED_GN_FINALIZE and not APPLY_FROM_PARTIALS)
             if stats is None:
-                stats = K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
+                stats = ("partial", partial, parts, gn_eps) if APPLY_FROM_PARTIALS else K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
             return y, stats
         y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
-        if FUSED_GN_FINALIZE:
+        if FUSED_GN_FINALIZE and not APPLY_FROM_PARTIALS:
             return y, K.gn_stats_fused(y, gn_groups, gn_eps)
         partial, parts = K.gn_stats_partial(y, gn_groups)
+        if APPLY_FROM_PARTIALS:
+            return y, ("partial", partial, parts, gn_eps)
         return y, K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
 
 
@@ -193,6 +196,8 @@ def _basicblock_conv_and_stats(self, x, in_layout=L.LAYOUT_NHWC):
 def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
     y, stats = y_stats
     nm = self.norm
+    if isinstance(stats, tuple):  # ("partial", records, parts, eps): finalize inside the apply pass
+        return K.gn_apply_partial(y, stats[1], stats[2], nm.weight, nm.bias, nm.num_groups, stats[3], int(self.has_act), residual, emb, emb_stride, out=y)
     return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
 
 
