@@ -161,14 +161,26 @@ def main():
         total_ms = sum(v[0] for v in tab.values())
         alg = fl / (ms * 1e-3) / 1e12          # algorithmic FLOPs of the reference convolutions / launch time
         if prec == 0:
+            mode = 0
             name, peak, executed = "conv_igemm_kernel<MODE 0> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv)", PEAK_FP32_TFLOPS, 1
         else:   # six bf16 MFMA terms per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs
             mode = 3 if (prec == 1 and BLK.PRESPLIT_WEIGHTS) else prec
             name, peak, executed = "conv_igemm_kernel<..., MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate%s)" % (
                 mode, "; weights pre-split at load" if mode == 3 else ""), PEAK_BF16_TFLOPS, 6
         ach = alg * executed
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live, so they come from the committed
+            # rocprofv3 passes over this same command (scripts/pmc_bench_traffic.sh -> profiles/pmc_bench_traffic.json)
+            pj = json.load(open(Path(__file__).resolve().parent / "profiles" / "pmc_bench_traffic.json"))
+            cand = [e for e in pj["kernels"] if "conv_igemm_kernel" in e["kernel"] and (", %d>" % mode if prec else ", 0>") in e["kernel"]]
+            if cand:
+                traffic = max(cand, key=lambda e: e["total_fetch_KiB_raw"])["hbm_bytes_per_launch"]
+                traffic_src = "profiles/pmc_bench_traffic.json: " + pj["method"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch of the most frequent conv tile",
+                "traffic_source": traffic_src, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
                 "algorithmic_tflops": round(alg, 2), "executed_over_algorithmic": executed,
                 "share_of_gpu_time": round(ms / total_ms, 4),
                 "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])}}

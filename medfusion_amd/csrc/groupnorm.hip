@@ -11,16 +11,26 @@ using namespace mf;
 
 namespace {
 
-__global__ void gn_stats_final_kernel(const double* __restrict__ partial, float* __restrict__ stats, int NG, int G, int chunks, double count,
-                                      float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= NG) return;
-  const int n = i / G, g = i - n * G;
+// 16 lanes per (sample, group): each lane sums every 16th partial record, a 16-lane butterfly combines them (one memory latency
+// instead of `chunks` of them: the records were just written by another kernel, so every load is an L2/HBM round trip)
+__global__ __launch_bounds__(256) void gn_stats_final_kernel(const double* __restrict__ partial, float* __restrict__ stats, int NG, int G, int chunks,
+                                                              double count, float eps) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 4, l = t & 15;
   double s = 0, q = 0;
-  for (int c = 0; c < chunks; ++c) {
-    const double* p = partial + (((long)n * chunks + c) * G + g) * 2;
-    s += p[0]; q += p[1];
+  if (i < NG) {
+    const int n = i / G, g = i - n * G;
+    for (int c = l; c < chunks; c += 16) {
+      const double* p = partial + (((long)n * chunks + c) * G + g) * 2;
+      s += p[0]; q += p[1];
+    }
   }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  if (i >= NG || l != 0) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0) var = 0;
@@ -155,7 +165,7 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
   int rc = check_launch("gn_stats_partial");
   if (rc) return rc;
   const int NG = N * G;
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG + 127) / 128), dim3(128), 0, s, reinterpret_cast<const double*>(workspace), stats, NG, G,
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double*>(workspace), stats, NG, G,
                      chunks, (double)HW * (C / G), eps);
   return check_launch("gn_stats_final");
 }
@@ -200,7 +210,7 @@ int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, in
   hipStream_t s = (hipStream_t)stream;
   const int NG = N * G;
   ProfScope ps(MF_FAM_GN_STATS, s, 0, 16.0 * NG * parts);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG + 127) / 128), dim3(128), 0, s, partial, stats, NG, G, parts, (double)HW * (C / G), eps);
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, partial, stats, NG, G, parts, (double)HW * (C / G), eps);
   return check_launch("gn_finalize");
 }
 
