@@ -55,6 +55,7 @@ struct ConvP {
   double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
   int gn_groups, gn_parts, gn_cpg;
   GnFinal gn_fin;                   // optional last-arriver finalize -> stats[n][g] = {mean, rstd}
+  int fastg;                        // fast gather usable: no fused nearest-x2 gather, < 2^24 source pixels, < 2^22 channels per source
 };
 
 // bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
@@ -88,7 +89,7 @@ __device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, 
   h = u32x2{h0, h1}; m = u32x2{m0, m1}; l = u32x2{l0, l1};
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
@@ -126,7 +127,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
 
   const int srow = tid / TPR, skoff = (tid % TPR) * 4;
 
-  int a_n[PA], a_iy0[PA], a_ix0[PA];
+  // FG ("fast gather", host: no fused nearest-x2 gather, < 2^24 source pixels): per row the pixel index of tap (0,0) and a bit mask
+  // of the taps that fall outside the image; per chunk the gather address is then add + 24-bit mad + bfe + or instead of the
+  // generic coordinate arithmetic (2 compares, 2 full 32-bit multiplies, selects)
+  int a_n[PA], a_iy0[PA], a_ix0[PA], a_pix[PA], a_inv[PA];
+  const unsigned skoff4 = (unsigned)skoff * 4u;
 #pragma unroll
   for (int q = 0; q < PA; ++q) {
     const int m = m0 + q * RPP + srow;
@@ -149,6 +154,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       a_n[q] = 0;
       a_iy0[q] = -(1 << 28);  // rows past M: always "out of bounds" -> zeros (address clamps to pixel 0 of image 0)
       a_ix0[q] = 0;
+    }
+    if constexpr (FG) {
+      unsigned valid = 0;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {  // tap index ty * KW + tx (KH, KW <= 3)
+          const bool in = ty < p.KH && tx < p.KW && (unsigned)(a_iy0[q] + ty) < (unsigned)p.Heff && (unsigned)(a_ix0[q] + tx) < (unsigned)p.Weff;
+          valid |= (in ? 1u : 0u) << (ty * p.KW + tx);
+        }
+      a_inv[q] = (int)~valid;  // bits >= KH*KW stay set: bit 31 is the "chunk past the end" tap
+      a_pix[q] = (a_n[q] + a_iy0[q]) * p.Win + a_ix0[q];
+    } else {
+      a_inv[q] = a_pix[q] = 0;
     }
   }
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.bytesw, 0x00020000);
@@ -195,20 +214,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
     const bool first_ = c0_ < p.C1;                                                                          \
     const int Cs_ = first_ ? p.C1 : p.C2;                                                                    \
     const int coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                   \
+    const int tapoff_ = ky * p.Win + kx, tsel_ = lv_ ? ky * p.KW + kx : 31;                                  \
+    const unsigned Cs4_ = (unsigned)Cs_ * 4u, cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;             \
     const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
         const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000);
 #define MF_GLOAD_A(SET, Q)                                                                                   \
   {                                                                                                          \
-    const int iy = a_iy0[Q] + ky, ix = a_ix0[Q] + kx;                                                        \
-    const bool ok = lv_ && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;               \
-    const int sy = iy >> p.ups, sx = ix >> p.ups;                                                            \
-    const unsigned off = (unsigned)(((a_n[Q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                        \
-    ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
+    if constexpr (FG) {                                                                                      \
+      const unsigned off = (__umul24((unsigned)(a_pix[Q] + tapoff_), Cs4_) + (cb4_ + skoff4)) |              \
+                           (unsigned)__builtin_amdgcn_sbfe(a_inv[Q], (unsigned)tsel_, 1u);                   \
+      ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 0));         \
+    } else {                                                                                                 \
+      const int iy = a_iy0[Q] + ky, ix = a_ix0[Q] + kx;                                                      \
+      const bool ok = lv_ && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;             \
+      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                          \
+      const unsigned off = (unsigned)(((a_n[Q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                      \
+      ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
+    }                                                                                                        \
   }
 #define MF_GLOAD_W(SET, Q)                                                                                   \
-  _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
-    rw##SET[Q][c] = __builtin_amdgcn_raw_buffer_load_b128(                                                   \
-        rsw, lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 6u + c * 16u : 0xFFFFFFF0u, 0, 0);
+  {  /* one address per row (select + add), the three 16-byte pieces through the instruction's immediate offset */ \
+    const unsigned wv_ = lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 6u : 0xFFFFFF00u; \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                            \
+      rw##SET[Q][c] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wv_ + c * 16u, 0, 0);                       \
+  }
 #define MF_GLOAD_B1(SET, Q)                                                                                  \
   rb##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
       rsw, lv_ ? wboff + (unsigned)((Q) * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0));
@@ -327,7 +356,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       float* sa_ = As + (buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                            \
       float* sb_ = Bs + (buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                            \
       unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
-      int coff_ = 0, Cs_ = 0;                                                                                        \
+      int coff_ = 0, Cs_ = 0, tapoff_ = 0, tsel_ = 31;                                                               \
+      unsigned Cs4_ = 0, cb4_ = 0;                                                                                   \
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
       float* sw_ = Bs + (buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                                  \
@@ -341,6 +371,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         lv_ = (KC) < kc_end;                                                                                         \
         Cs_ = first_ ? p.C1 : p.C2;                                                                                  \
         coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                 \
+        tapoff_ = ky * p.Win + kx; tsel_ = lv_ ? ky * p.KW + kx : 31;                                                \
+        Cs4_ = (unsigned)Cs_ * 4u; cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;                                \
         rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
       }                                                                                                              \
       MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
@@ -848,18 +880,23 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32, int MODE = 0>
-int launch_igemm(const ConvP& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
+int launch_igemm_fg(const ConvP& p, hipStream_t s) {
   constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
+}
+
+template <int BM, int BN, int WM, int WN, int BK = 32, int MODE = 0>
+int launch_igemm(const ConvP& p, hipStream_t s) {
+  return p.fastg ? launch_igemm_fg<BM, BN, WM, WN, BK, MODE, true>(p, s) : launch_igemm_fg<BM, BN, WM, WN, BK, MODE, false>(p, s);
 }
 
 }  // namespace
@@ -967,6 +1004,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
   p.gn_fin = GnFinal{};
+  p.fastg = (p.ups == 0 && (long)d->N * d->Hin * d->Win < (1L << 24) && d->C1 < (1 << 22) && d->C2 < (1 << 22)) ? 1 : 0;
+  if (getenv("MF_CONV_GENERIC_GATHER")) p.fastg = 0;  // A/B switch (scripts, tests)
   const int HWo = pl.Hout * pl.Wout;
   if (gn.stats) {  // last-arriver finalize (gn.counter: zero on entry, zero again on exit)
     if (pl.igemm && pl.splitk == 1)
