@@ -1,0 +1,63 @@
+"""Host-side planning logic of the convolution C-ABI (no GPU: these entry points never launch anything)."""
+import ctypes as C
+
+import pytest
+
+from medfusion_amd import kernels as K
+from medfusion_amd import lib as L
+
+
+def _d(n, h, w, c1, c2, co, k=3, stride=1, ups=0, prec=0, tile=0, sk=0, lin=L.LAYOUT_NHWC, lout=L.LAYOUT_NHWC):
+    return K.make_conv_desc(n, h, w, c1, c2, co, k, stride, 1 if k == 3 else 0, ups, lin, lout, tile_hint=tile, splitk_hint=sk, precision=prec)
+
+
+def test_which_convs_run_on_the_implicit_gemm_kernel():
+    lib = L.load()
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256))) == 1          # UNet 32^2 level
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 8, 8, 1024, 1024, 1024))) == 1       # two-source out block
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 8, 0, 256, lin=L.LAYOUT_NCHW))) == 0   # in_conv: small-Cin kernel
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 8, k=1, lout=L.LAYOUT_NCHW))) == 0  # outc: direct kernel
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(2, 8, 8, 48, 0, 64))) == 0                # Cin % 32 != 0
+
+
+@pytest.mark.parametrize("prec", [0, 1, 2, 3])
+def test_split_k_workspace_and_gn_parts_are_consistent(prec):
+    lib = L.load()
+    for shape in [(16, 32, 32, 256, 0, 256), (16, 16, 16, 512, 0, 512), (16, 8, 8, 1024, 1024, 1024), (4, 64, 64, 256, 0, 256), (1, 256, 256, 64, 0, 64)]:
+        d = _d(*shape, prec=prec)
+        ws = lib.mf_conv2d_workspace_bytes(C.byref(d))
+        n, h, w, _, _, co = shape
+        out_bytes = n * h * w * co * 4
+        assert ws % out_bytes == 0                      # 0 (no split-K) or splitk slabs of the output size
+        sk = ws // out_bytes
+        assert sk == 0 or 2 <= sk <= 16
+        parts = lib.mf_conv2d_gn_parts(C.byref(d), 32)
+        assert 0 < parts <= max(16, h * w // 64)       # every large conv of the path can emit GroupNorm partials
+        if prec:                                         # split modes: one accumulation chain <= 96 chunks of 32
+            chunks = 9 * (shape[3] + shape[4]) // 32
+            assert chunks / max(sk, 1) <= 96
+
+
+def test_subpixel_form_availability():
+    lib = L.load()
+    assert lib.mf_conv2d_subpixel_ok(C.byref(_d(16, 16, 16, 512, 0, 512, ups=2))) == 1
+    assert lib.mf_conv2d_subpixel_ok(C.byref(_d(2, 5, 6, 32, 0, 32, ups=2))) == 0     # Hin*Win % 64 != 0 -> gather form
+    assert lib.mf_conv2d_subpixel_ok(C.byref(_d(16, 16, 16, 512, 0, 512, ups=1))) == 0  # not asked for
+
+
+def test_bad_descriptors_are_refused_without_a_gpu():
+    lib = L.load()
+    assert lib.mf_conv2d_workspace_bytes(C.byref(_d(16, 32, 32, 256, 0, 256, prec=7))) == 0   # unknown precision -> plan fails
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, k=5))) == 0
+    assert b"" != lib.mf_last_error()
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, prec=1, tile=24))) == 0  # BK = 64 tile is fp32-only
+
+
+def test_precision_enum_matches_header():
+    import re
+    from pathlib import Path
+    txt = (Path(__file__).resolve().parents[1] / "include" / "medfusion_hip.h").read_text()
+    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3 = (\d), MF_CONV_FP32_SPLIT3_CHUNKSUM = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d) \}", txt)
+    assert m and [int(v) for v in m.groups()] == [0, 1, 2, 3]
+    from medfusion_amd import blocks as BLK
+    assert BLK.CONV_PRECISION in (0, 1, 2)
