@@ -90,14 +90,21 @@ __device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, 
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
   // MODE 1: [3 pieces][32 bf16] = 48 words + 4: pitch/4 = 13 is odd, so the 16 rows of a quarter-wave b128 read hit distinct banks.
   constexpr int LDK = MODE == 0 ? BK + 4 : 52;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
-  constexpr bool WS = MODE == 3;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
+  // MODE 4 = MODE 3 with ONE LDS buffer and 4-wave workgroups, two of them per CU: the fragments of a chunk are pulled into
+  // registers (barrier | 24 ds_read_b128 | barrier), then the same buffer is refilled with the next chunk while the MFMAs run from
+  // registers.  The two waves of a SIMD then belong to DIFFERENT workgroups with their own barrier cadence, so one computes while the
+  // other sits in its barrier/fragment-read window (with two waves of ONE workgroup per SIMD both sit there at the same time: the
+  // matrix pipe was 59 % busy, profiles/r01_pmc_conv_split.csv).
+  constexpr bool SB = MODE == 4;
+  constexpr int NBUF = SB ? 1 : 2;
+  constexpr bool WS = MODE == 3 || MODE == 4;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
   constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
@@ -109,8 +116,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
   static_assert(!WS || BN % RPW == 0, "tile/threads mismatch (pre-split weights)");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                  // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;   // [2][BN][LDK]
+  float* As = smem;                     // [NBUF][BM][LDK]
+  float* Bs = smem + NBUF * BM * LDK;   // [NBUF][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -353,16 +360,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                 \
         _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
           fb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));     \
-      float* sa_ = As + (buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                            \
-      float* sb_ = Bs + (buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                            \
+      float* sa_ = As + (SB ? 0 : buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                   \
+      float* sb_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                   \
       unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
       int coff_ = 0, Cs_ = 0, tapoff_ = 0, tsel_ = 31;                                                               \
       unsigned Cs4_ = 0, cb4_ = 0;                                                                                   \
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
-      float* sw_ = Bs + (buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                                  \
-      constexpr int NM = 12 * TM * TN, RU = TM + TN, UA = 3 * (PA - 1);                                              \
-      constexpr int UI = RU + UA + (WS ? PW : 3 * PB);  /* A item 0 runs before the MFMAs */                         \
+      float* sw_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                         \
+      constexpr int NM = 12 * TM * TN, RU = SB ? 0 : TM + TN, UA = SB ? 3 * PA : 3 * (PA - 1);                       \
+      constexpr int UI = RU + UA + (WS ? PW : 3 * PB);  /* double-buffered: A item 0 runs before the MFMAs */        \
       static_assert(UI <= 2 * NM, "units per MFMA slot");                                                            \
       { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
         MF_ADVANCE();                                                                                                \
@@ -375,7 +382,17 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
         Cs4_ = (unsigned)Cs_ * 4u; cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;                                \
         rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
       }                                                                                                              \
-      MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
+      if constexpr (SB) { /* all fragments of the chunk into registers, then the buffer is free for chunk k+1 */      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
+            fa[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
+            fb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
+        __syncthreads();                                                                                             \
+      } else {                                                                                                       \
+        MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
+      }                                                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       f32x16 accc[TM][TN];                                                                                           \
       _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
@@ -407,7 +424,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
             _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];                            \
       }                                                                                                              \
     }                                                                                                                \
-    buf ^= 1;                                                                                                        \
+    if (!SB) buf ^= 1;                                                                                               \
   }
 // work unit U of a split-mode chunk (see MF_COMPUTE): [0, RU) second-step fragment reads of one 32-row sub-tile; then 3 units
 // per staging item (items 1..NI-1).
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvP p) 
           fb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
       }                                                                                                              \
     } else if (u < RU + UA) {                                                                                        \
-      MF_ITEM_A(1 + (u - RU) / 3, (u - RU) % 3, SET)                                                                 \
+      MF_ITEM_A((SB ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                                      \
     } else if constexpr (WS) {                                                                                       \
       MF_ITEM_W(u - RU - UA, SET)                                                                                    \
     } else {                                                                                                         \
@@ -778,6 +795,7 @@ struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
     {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32}, {10, 256, 128, 4, 2, 32},
+    {11, 128, 128, 2, 2, 32}, {12, 64, 128, 2, 2, 32}, {13, 128, 64, 2, 2, 32},  // MF_CONV_FP32_SPLIT3_W3 only: single LDS buffer, two 4-wave workgroups per CU
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
@@ -832,6 +850,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     MF_REQUIRE(d->C1 % c->BK == 0 && d->C2 % c->BK == 0, MF_EINVAL, "conv: tile_hint %d needs channel counts divisible by %d", d->tile_hint, c->BK);
     MF_REQUIRE(d->precision == MF_CONV_FP32 || c->BK == 32, MF_EINVAL, "conv: tile_hint %d is not built for the split-bf16 mode", d->tile_hint);
+    MF_REQUIRE(d->precision == MF_CONV_FP32_SPLIT3_W3 || c->id < 11 || c->id > 13, MF_EINVAL, "conv: tile_hint %d needs MF_CONV_FP32_SPLIT3_W3", d->tile_hint);
     pl->cfg = *c;
   } else {
     // From scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.txt): the 8-wave 128x128 tile (2 waves per SIMD inside
@@ -848,6 +867,12 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
       else if (d->Cout % 128 == 0 && pl->M >= 256 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 256)) id = 10;
       else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 3.0 && !(d->upsample == 2 && hw_src % 128)) id = 8;
       else if (d->Cout % 64 == 0) id = 4;
+      // pre-split weights: the single-buffer two-workgroups-per-CU forms win where Cout is too narrow for the 256-wide tile
+      // (VAE decoder levels: 128 ch 0.204 vs 0.227 ms, 64 ch 0.269 vs 0.280 ms; profiles/r01_conv_sweep_split.txt)
+      if (d->precision == MF_CONV_FP32_SPLIT3_W3 && d->tile_hint == 0) {
+        if (id == 10 && d->Cout == 128 && !(d->upsample == 2 && hw_src % 128)) id = 11;
+        else if (id == 4 && pl->M >= 4096 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) id = 13;
+      }
     } else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) {
       id = 8;                              // 8 waves, 128x128: best for every large 3x3 shape
     } else if (d->Cout % 64 == 0) {
@@ -883,7 +908,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
 template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
 int launch_igemm_fg(const ConvP& p, hipStream_t s) {
   constexpr int LDK = MODE == 0 ? BK + 4 : 52;
-  const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  const size_t lds = (size_t)(MODE == 4 ? 1 : 2) * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1081,6 +1106,9 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
         case 8: rc = launch_igemm<128, 128, 2, 4, 32, 3>(p, s); break;
         case 9: rc = launch_igemm<128, 256, 2, 4, 32, 3>(p, s); break;
         case 10: rc = launch_igemm<256, 128, 4, 2, 32, 3>(p, s); break;
+        case 11: rc = launch_igemm<128, 128, 2, 2, 32, 4>(p, s); break;
+        case 12: rc = launch_igemm<64, 128, 2, 2, 32, 4>(p, s); break;
+        case 13: rc = launch_igemm<128, 64, 2, 2, 32, 4>(p, s); break;
         default: set_error("conv: tile config %d is not built for the split-bf16 mode", pl.cfg.id); rc = MF_EINVAL;
       }
     } else if (d->precision == MF_CONV_FP32_SPLIT3) {

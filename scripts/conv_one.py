@@ -28,6 +28,8 @@ x2 = torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None
 wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
 b = torch.randn((co,), generator=g).to(dev)
 d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_hint=a.tile, splitk_hint=a.splitk, precision=a.precision)
+if a.precision == 3:
+    wt = K.split_conv_weight(wt)
 y = K.conv2d(x1, wt, b, d, x2=x2)
 for _ in range(5):
     K.conv2d(x1, wt, b, d, x2=x2, out=y)

@@ -106,8 +106,8 @@ def main():
         if not args.quick:
             tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
-                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 23: 128, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 256, 40: 128}[tile]
-                bm = {1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 23: 64, 24: 64, 27: 128, 28: 128, 37: 128, 38: 128, 39: 128, 40: 256}[tile]
+                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
+                bm = {1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
                 if ups == 2 and (h * w_) % bm:
                     continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):

@@ -105,12 +105,12 @@ def test_conv_igemm_split_bf16x3(dev, case, tile):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_conv_presplit_weights_bit_identical(dev, case, tile):
     """MF_CONV_FP32_SPLIT3_W3 (weights split into bf16 triplets once, mf_split_conv_weight_bf16x3) == MF_CONV_FP32_SPLIT3 bit for bit"""
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, stride, ups = case
-    bn = {1: 128, 2: 64, 3: 128, 4: 64, 6: 32, 7: 128, 8: 128, 9: 256, 10: 128}.get(tile, 32)
+    bn = {1: 128, 2: 64, 3: 128, 4: 64, 6: 32, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64}.get(tile, 32)
     if tile and co % bn:
         pytest.skip("tile does not divide Cout")
     x = _rand(f"cx{case}", (n, c1, h, w))
@@ -122,8 +122,9 @@ def test_conv_presplit_weights_bit_identical(dev, case, tile):
     x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
     wp = K.pack_conv_weight(wt.to(dev))
     w3 = K.split_conv_weight(wp)
+    ref_tile = {11: 1, 12: 3, 13: 2}.get(tile, tile)   # 11-13: the single-LDS-buffer forms of 1 / 3 / 2 (pre-split weights only)
     for sk in ([0] if tile == 0 else [0, 1, 3]):
-        d1 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=1)
+        d1 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=ref_tile, splitk_hint=sk, precision=1)
         d3 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=3)
         assert K.conv_is_igemm(d3)
         assert torch.equal(K.conv2d(xd, wp, b.to(dev), d1, x2=x2d), K.conv2d(xd, w3, b.to(dev), d3, x2=x2d)), (case, tile, sk)
