@@ -94,8 +94,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the denoise iteration as a captured hipGraph (default for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2],
-                    help="arithmetic of the conv kernel (MF_CONV_*): 1 = fp32 via exact 3 x bf16 split (default), 0 = fp32 MFMA, 2 = split + chunk sums")
+    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2, 4],
+                    help="arithmetic of the conv kernel (MF_CONV_*): 1 = fp32 via exact 3 x bf16 split (default), 0 = fp32 MFMA, 2 = split + chunk sums, "
+                         "4 = opt-in REDUCED precision (bf16 operands): not the headline metric")
     ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed step on the other conv arithmetic")
     args = ap.parse_args()
 
@@ -163,6 +164,9 @@ def main():
         if prec == 0:
             mode = 0
             name, peak, executed = "conv_igemm_kernel<MODE 0> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv)", PEAK_FP32_TFLOPS, 1
+        elif prec == 4:
+            mode = 5
+            name, peak, executed = "conv_igemm_kernel<..., MODE 5> (REDUCED precision: operands rounded to bf16, one MFMA term, fp32 accumulate)", PEAK_BF16_TFLOPS, 1
         else:   # six bf16 MFMA terms per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs
             mode = 3 if (prec == 1 and BLK.PRESPLIT_WEIGHTS) else prec
             name, peak, executed = "conv_igemm_kernel<..., MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate%s)" % (
@@ -187,7 +191,7 @@ def main():
     alt = None
     if not args.no_alt_path and rank == 0 and world == 1:
         # the same step on the other conv arithmetic, timed the same way (1 warm-up + max(1, steps) runs), for comparison
-        BLK.CONV_PRECISION = 0 if prec else 1
+        BLK.CONV_PRECISION = 0 if prec in (1, 2) else 1
         one_step(2000)
         fence()
         t1 = time.perf_counter()
@@ -207,7 +211,7 @@ def main():
             "metric": "images/sec at 256x256, 150 DDIM steps (DiffusionPipeline.sample incl. VAE decode)",
             "value": round(ips, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "conv_arithmetic": {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "fp32 operands split exactly into 3 bf16 terms, 6 product terms on the bf16 MFMA, fp32 accumulate (error vs fp64 <= the fp32-MFMA kernel's: tests/test_kernels_gpu.py)", 2: "as 1, per-chunk sums added by the VALU"}[prec],
+            "dtype": "bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)" if prec == 4 else "f32", "conv_arithmetic": {4: "REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32", 0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "fp32 operands split exactly into 3 bf16 terms, 6 product terms on the bf16 MFMA, fp32 accumulate (error vs fp64 <= the fp32-MFMA kernel's: tests/test_kernels_gpu.py)", 2: "as 1, per-chunk sums added by the VALU"}[prec],
             "data": "synthetic (seeded weights of the published architecture, device Philox noise)",
             "config": {"workload": f"{args.workload}: {B} images/GPU, latent {wl['latent']}, {wl['steps']} {'DDIM' if wl['use_ddim'] else 'DDPM'} iterations, "
                                    f"{'uncond' if cond is None else 'cond %d-class g=%s' % (wl['classes'], wl['guidance'])}, decode to {8 * wl['latent'][1]}x{8 * wl['latent'][2]}",

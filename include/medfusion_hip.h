@@ -68,8 +68,11 @@ typedef struct MfConvDesc {
  *   (round-to-nearest): 2-4x smaller error than MF_CONV_FP32, ~2 % slower than MF_CONV_FP32_SPLIT3.
  * MF_CONV_FP32_SPLIT3_W3: MF_CONV_FP32_SPLIT3 (bit-identical results) with `w_packed` pointing to the weights ALREADY split:
  *   mf_split_conv_weight_bf16x3 turns either fp32 packing ([rows][K]) into [rows][K/8][3 pieces][8] bf16 (6 bytes per weight) once
- *   at load time; the kernel then moves them to LDS without any arithmetic.  Implicit-GEMM path only (mf_conv2d_is_igemm). */
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3 };
+ *   at load time; the kernel then moves them to LDS without any arithmetic.  Implicit-GEMM path only (mf_conv2d_is_igemm).
+ * MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (round to nearest even), one MFMA term, fp32
+ *   accumulate; `w_packed` points to weights converted by mf_convert_conv_weight_bf16 ([rows][K] bf16).  Error vs fp64 ~3e-3 per
+ *   convolution (2^-9 per operand); never selected by default, has its own tolerance in the tests.  Implicit-GEMM path only. */
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],
@@ -80,6 +83,8 @@ int mf_conv2d_subpixel_ok(const MfConvDesc* d);
 int mf_conv2d_is_igemm(const MfConvDesc* d);
 /* rows = Cout (x4 for the sub-pixel packing); out: rows * K * 6 bytes */
 int mf_split_conv_weight_bf16x3(const float* w_packed, void* w_split, long rows, int K, void* stream);
+/* out: rows * K * 2 bytes (MF_CONV_BF16) */
+int mf_convert_conv_weight_bf16(const float* w_packed, void* w_bf16, long rows, int K, void* stream);
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
 /* y = conv(x1 (++ x2 on channels), w) + bias.  bias may be NULL.  workspace >= mf_conv2d_workspace_bytes. */
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,

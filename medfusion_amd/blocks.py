@@ -48,6 +48,7 @@ class _Packed:
         self._key = None
         self._w = None
         self._w3 = None
+        self._wb = None
         self._subpixel = subpixel
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
@@ -58,8 +59,16 @@ class _Packed:
                 w = w.unsqueeze(-1)
             self._w = K.pack_upconv_weight(w) if self._subpixel else K.pack_conv_weight(w)
             self._w3 = None
+            self._wb = None
             self._key = key
         return self._w
+
+    def get_bf16(self, weight: torch.Tensor) -> torch.Tensor:
+        """the same weights rounded to bf16 (opt-in MF_CONV_BF16)"""
+        wp = self.get(weight)
+        if self._wb is None:
+            self._wb = K.convert_conv_weight_bf16(wp)
+        return self._wb
 
     def get_split(self, weight: torch.Tensor) -> torch.Tensor:
         """the same weights as bf16 triplets (MF_CONV_FP32_SPLIT3_W3), derived once from the fp32 packing"""
@@ -74,7 +83,8 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*):
 #   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
 #     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
-#     per-chunk sums added by the VALU (the most accurate of the three).  Read per call: set blocks.CONV_PRECISION or the env var.
+#     per-chunk sums added by the VALU (the most accurate of the three);  4: opt-in REDUCED precision (operands rounded to bf16, one
+#     MFMA term; its own tolerance).  Read per call: set blocks.CONV_PRECISION or the env var.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
 APPLY_FROM_PARTIALS = bool(int(os.environ.get("MEDFUSION_APPLY_FROM_PARTIALS", "0")))  # GroupNorm finalize inside the apply pass (A/B switch)
 PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
@@ -114,11 +124,13 @@ class Conv(nn.Module):
                     d = d2
             if d.precision == 1 and PRESPLIT_WEIGHTS and rows is None and K.conv_is_igemm(d):
                 d.precision = 3  # MF_CONV_FP32_SPLIT3_W3
+            if d.precision == 4 and (rows is not None or not K.conv_is_igemm(d)):
+                d.precision = 0  # the small / edge convolutions are not on the implicit-GEMM kernel: plain fp32
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
             self._descs[key] = ent
         d, parts = ent
         pk = self._packed_sub if d.upsample == 2 else self._packed
-        wp = pk.get_split(self.weight) if d.precision == 3 else pk.get(self.weight)
+        wp = pk.get_split(self.weight) if d.precision == 3 else pk.get_bf16(self.weight) if d.precision == 4 else pk.get(self.weight)
         b = self.bias
         if rows is not None:  # output-channel slice (learned-variance head split)
             wp, b = wp[rows], b[rows]

@@ -80,6 +80,15 @@ __device__ __forceinline__ void split2_bf16x3(const float x0, const float x1, un
   m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
   l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned round_bf16x2(const float x0, const float x1) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  const bf16x2 v = {(__bf16)x0, (__bf16)x1};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ u32x2 round_bf16x4(const f32x4 v) {
+  const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  return u32x2{round_bf16x2(x0, x1), round_bf16x2(x2, x3)};
+}
 __device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
   // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT read element 0 every time)
   const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   constexpr int NT = WM * WN * 64;
   // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
   // MODE 1: [3 pieces][32 bf16] = 48 words + 4: pitch/4 = 13 is odd, so the 16 rows of a quarter-wave b128 read hit distinct banks.
-  constexpr int LDK = MODE == 0 ? BK + 4 : 52;
+  constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);  // MODE 5: 32 bf16 = 16 words + 4 (pitch/4 = 5, odd)
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
   // MODE 4 = MODE 3 with ONE LDS buffer and 4-wave workgroups, two of them per CU: the fragments of a chunk are pulled into
@@ -104,7 +113,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // matrix pipe was 59 % busy, profiles/r01_pmc_conv_split.csv).
   constexpr bool SB = MODE == 4;
   constexpr int NBUF = SB ? 1 : 2;
-  constexpr bool WS = MODE == 3 || MODE == 4;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
+  // MODE 5 = MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (RNE), one MFMA term, fp32 accumulate; weights
+  // arrive already converted (mf_convert_conv_weight_bf16).  Same kernel with NP = 1 piece instead of 3.
+  constexpr int NP = MODE == 5 ? 1 : 3, NTERM = MODE == 5 ? 1 : 6;
+  constexpr bool WS = MODE == 3 || MODE == 4 || MODE == 5;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
   constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;
   const unsigned wboff = (unsigned)((phase_t * p.Cout + n0 + srow) * p.K + skoff) * 4u;
   const int wrow = tid >> 2, wo = tid & 3;
-  const unsigned wsoff = (unsigned)((phase_t * p.Cout + n0 + wrow) * p.K) * 6u + (unsigned)wo * 48u;  // 6 bytes per weight
+  const unsigned wsoff = (unsigned)((phase_t * p.Cout + n0 + wrow) * p.K) * (2u * NP) + (unsigned)wo * (16u * NP);  // 2 NP bytes per weight
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // Two register sets: set 0 holds chunk 0 during the cold start only, set 1 is the steady-state prefetch register set
   // (a gather running TWO chunks ahead through both sets was built and measured: -1...+1 %, not kept).
   f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
-  u32x4 rw0[PW][3], rw1[PW][3];
+  u32x4 rw0[PW][NP], rw1[PW][NP];
 
 // (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
 // Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
@@ -240,9 +252,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     }                                                                                                        \
   }
 #define MF_GLOAD_W(SET, Q)                                                                                   \
-  {  /* one address per row (select + add), the three 16-byte pieces through the instruction's immediate offset */ \
-    const unsigned wv_ = lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 6u : 0xFFFFFF00u; \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                            \
+  {  /* one address per row (select + add), the 16-byte pieces through the instruction's immediate offset */  \
+    const unsigned wv_ = lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * (2u * NP) : 0xFFFFFF00u; \
+    _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                           \
       rw##SET[Q][c] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wv_ + c * 16u, 0, 0);                       \
   }
 #define MF_GLOAD_B1(SET, Q)                                                                                  \
@@ -291,16 +303,20 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       float* a_ = As + (BUF) * BM * LDK + srow * LDK + (skoff >> 1);                                         \
       float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + (skoff >> 1);                                         \
       _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                       \
-        u32x2 h_, m_, l_;                                                                                    \
-        split_bf16x3(ra##SET[q], h_, m_, l_);                                                                \
-        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = h_;                                                  \
-        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 16) = m_;                                             \
-        *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 32) = l_;                                             \
+        if constexpr (NP == 1) {                                                                             \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = round_bf16x4(ra##SET[q]);                          \
+        } else {                                                                                             \
+          u32x2 h_, m_, l_;                                                                                  \
+          split_bf16x3(ra##SET[q], h_, m_, l_);                                                              \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = h_;                                                \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 16) = m_;                                           \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 32) = l_;                                           \
+        }                                                                                                    \
       }                                                                                                      \
       if constexpr (WS) {                                                                                    \
         float* w_ = Bs + (BUF) * BN * LDK + wrow * LDK + wo * 4;                                             \
         _Pragma("unroll") for (int q = 0; q < PW; ++q)                                                       \
-          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                      \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                     \
             *reinterpret_cast<u32x4*>(w_ + q * RPW * LDK + c * 16) = rw##SET[q][c];                          \
       } else {                                                                                               \
         _Pragma("unroll") for (int q = 0; q < PB; ++q) {                                                     \
@@ -353,12 +369,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     } else { /* two 16-deep MFMA steps per chunk; lane half hf reads the 8 consecutive k [16 s + 8 hf, +8) of each piece.   \
                 The chunk's other work (3-way split + LDS store of chunk k+1, fragment reads of the second step, gather of      \
                 chunk k+3) is cut into small units pinned BETWEEN the MFMAs (sched_barrier fences). */                          \
-      bf16x8 fa[2][TM][3], fb[2][TN][3];                                                                             \
+      bf16x8 fa[2][TM][NP], fb[2][TN][NP];                                                                             \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
           fa[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16));     \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                 \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
           fb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));     \
       float* sa_ = As + (SB ? 0 : buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                   \
       float* sb_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                   \
@@ -368,9 +384,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
       float* sw_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                         \
-      constexpr int NM = 12 * TM * TN, RU = SB ? 0 : TM + TN, UA = SB ? 3 * PA : 3 * (PA - 1);                       \
+      constexpr int NM = 2 * NTERM * TM * TN, RU = SB ? 0 : TM + TN, UA = SB ? 3 * PA : 3 * (PA - 1);                       \
       constexpr int UI = RU + UA + (WS ? PW : 3 * PB);  /* double-buffered: A item 0 runs before the MFMAs */        \
-      static_assert(UI <= 2 * NM, "units per MFMA slot");                                                            \
+      static_assert(UI <= 8 * NM, "units per MFMA slot");                                                            \
       { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
         MF_ADVANCE();                                                                                                \
         const int c0_ = cc * BK;                                                                                     \
@@ -384,10 +400,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       }                                                                                                              \
       if constexpr (SB) { /* all fragments of the chunk into registers, then the buffer is free for chunk k+1 */      \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
             fa[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
-          _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                              \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
             fb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
         __syncthreads();                                                                                             \
       } else {                                                                                                       \
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       f32x16 accc[TM][TN];                                                                                           \
       _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
         constexpr int kCA[6] = {2, 0, 1, 1, 0, 0}, kCB[6] = {0, 2, 1, 0, 1, 0};  /* smallest terms first */         \
-        const int j_ = n % TN, i_ = (n / TN) % TM, t_ = (n / (TN * TM)) % 6, s_ = n / (TN * TM * 6);                 \
+        const int j_ = n % TN, i_ = (n / TN) % TM, t_ = NTERM == 1 ? 5 : (n / (TN * TM)) % 6, s_ = n / (TN * TM * NTERM);                 \
         if (kAblate & 32) {                                                                                          \
         } else if (FLUSH) {                                                                                          \
           if (s_ == 0 && t_ == 0) {                                                                                  \
@@ -415,6 +431,14 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
           const int ulo_ = (n * UI + NM - 1) / NM, uhi_ = ((n + 1) * UI + NM - 1) / NM;                              \
           if (ulo_ < uhi_) { MF_UNIT(ulo_, SET, KC) }                                                                \
           if (ulo_ + 1 < uhi_) { MF_UNIT(ulo_ + 1, SET, KC) }                                                        \
+          if constexpr (UI > 2 * NM) { /* the one-term bf16 mode has few MFMAs: up to 8 units per slot */            \
+            if (ulo_ + 2 < uhi_) { MF_UNIT(ulo_ + 2, SET, KC) }                                                      \
+            if (ulo_ + 3 < uhi_) { MF_UNIT(ulo_ + 3, SET, KC) }                                                      \
+            if (ulo_ + 4 < uhi_) { MF_UNIT(ulo_ + 4, SET, KC) }                                                      \
+            if (ulo_ + 5 < uhi_) { MF_UNIT(ulo_ + 5, SET, KC) }                                                      \
+            if (ulo_ + 6 < uhi_) { MF_UNIT(ulo_ + 6, SET, KC) }                                                      \
+            if (ulo_ + 7 < uhi_) { MF_UNIT(ulo_ + 7, SET, KC) }                                                      \
+          }                                                                                                          \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
       }                                                                                                              \
@@ -434,10 +458,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     if (u < RU) {                                                                                                    \
       if (kAblate & 16) {                                                                                            \
       } else if (u < TM) {                                                                                           \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
           fa[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
       } else {                                                                                                       \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c)                                                                \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
           fb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
       }                                                                                                              \
     } else if (u < RU + UA) {                                                                                        \
@@ -453,7 +477,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
 #define MF_SPLIT_PARTS(V, PART, DST)                                                                                 \
     const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (V);                                  \
     const float e0_ = v_[0], e1_ = v_[1], e2_ = v_[2], e3_ = v_[3];                                                  \
-    if (kAblate & 1) {                                                                                               \
+    if constexpr (NP == 1) {                                                                                         \
+      if ((PART) == 0) h0_ = round_bf16x2(e0_, e1_);                                                                 \
+      if ((PART) == 1) h1_ = round_bf16x2(e2_, e3_);                                                                 \
+    } else if (kAblate & 1) {                                                                                        \
       if ((PART) == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
       if ((PART) == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
     } else {                                                                                                         \
@@ -463,8 +490,10 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     if ((PART) == 2 && !(kAblate & 2)) {                                                                             \
       float* d_ = (DST);                                                                                             \
       *reinterpret_cast<u32x2*>(d_) = u32x2{h0_, h1_};                                                               \
-      *reinterpret_cast<u32x2*>(d_ + 16) = u32x2{m0_, m1_};                                                          \
-      *reinterpret_cast<u32x2*>(d_ + 32) = u32x2{l0_, l1_};                                                          \
+      if constexpr (NP == 3) {                                                                                       \
+        *reinterpret_cast<u32x2*>(d_ + 16) = u32x2{m0_, m1_};                                                        \
+        *reinterpret_cast<u32x2*>(d_ + 32) = u32x2{l0_, l1_};                                                        \
+      }                                                                                                              \
     }
 #define MF_ITEM_A(Q, PART, SET)                                                                                      \
   {                                                                                                                  \
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
 #define MF_ITEM_W(Q, SET)                                                                                            \
   {                                                                                                                  \
     const int qw_ = (Q) < PW ? (Q) : 0;                                                                              \
-    _Pragma("unroll") for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(sw_ + qw_ * RPW * LDK + c * 16) = rw##SET[qw_][c]; \
+    _Pragma("unroll") for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(sw_ + qw_ * RPW * LDK + c * 16) = rw##SET[qw_][c]; \
     MF_GLOAD_W(SET, qw_)                                                                                             \
   }
 
@@ -790,6 +819,12 @@ __global__ void split_weight_kernel(const float* __restrict__ w, u32x4* __restri
   }
 }
 
+// [rows][K] fp32 -> [rows][K] bf16 (round to nearest even): the weights of the opt-in MF_CONV_BF16 mode
+__global__ void convert_weight_bf16_kernel(const float* __restrict__ w, u32x2* __restrict__ out, long quads) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < quads; o += stride) out[o] = round_bf16x4(*reinterpret_cast<const f32x4*>(w + o * 4));
+}
+
 // ------------------------------------------------------------------ host-side planning
 struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
@@ -812,7 +847,7 @@ int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
   MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
-  MF_REQUIRE(d->precision >= 0 && d->precision <= 3, MF_EINVAL, "conv: precision flag %d", d->precision);
+  MF_REQUIRE(d->precision >= 0 && d->precision <= 4, MF_EINVAL, "conv: precision flag %d", d->precision);
   MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
   MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
   MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
@@ -897,7 +932,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     }
     // split mode: the bf16 MFMA adds its 16 products and the accumulator with truncation; keep one accumulation chain short
     // (<= 96 chunks of 32) so that the error stays at the fp32-MFMA kernel's level (tests/test_kernels_gpu.py, scripts/split_accuracy.py)
-    if (d->precision != MF_CONV_FP32) while (nk / sk > 96 && sk < 16) sk *= 2;
+    if (d->precision != MF_CONV_FP32 && d->precision != MF_CONV_BF16) while (nk / sk > 96 && sk < 16) sk *= 2;
   }
   if (sk > nk) sk = nk;
   pl->nk_per_split = cdiv(nk, sk);
@@ -907,7 +942,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
 int launch_igemm_fg(const ConvP& p, hipStream_t s) {
-  constexpr int LDK = MODE == 0 ? BK + 4 : 52;
+  constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);
   const size_t lds = (size_t)(MODE == 4 ? 1 : 2) * (BM + BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -970,6 +1005,15 @@ int mf_split_conv_weight_bf16x3(const float* w_packed, void* out, long rows, int
   return check_launch("split_conv_weight");
 }
 
+int mf_convert_conv_weight_bf16(const float* w_packed, void* out, long rows, int K, void* stream) {
+  MF_REQUIRE(w_packed && out && rows > 0 && K > 0 && K % 8 == 0, MF_EINVAL, "convert_conv_weight_bf16: bad args (K %% 8 == 0)");
+  const long quads = rows * (K / 4);
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 6.0 * rows * K);
+  const int blocks = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
+  hipLaunchKernelGGL(convert_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x2*>(out), quads);
+  return check_launch("convert_conv_weight_bf16");
+}
+
 /* 1 if `d` (with upsample = 2) can run in the sub-pixel form, else 0 (then use upsample = 1 with the regular packing) */
 int mf_conv2d_subpixel_ok(const MfConvDesc* d) {
   Plan pl;
@@ -1009,8 +1053,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   int rc = make_plan(d, &pl);
   if (rc) return rc;
   MF_REQUIRE(x1 && w && y, MF_EINVAL, "conv: null pointer");
-  MF_REQUIRE(d->precision != MF_CONV_FP32_SPLIT3_W3 || pl.igemm, MF_EINVAL,
-             "conv: MF_CONV_FP32_SPLIT3_W3 (pre-split weights) exists on the implicit-GEMM path only (ask mf_conv2d_is_igemm)");
+  MF_REQUIRE((d->precision != MF_CONV_FP32_SPLIT3_W3 && d->precision != MF_CONV_BF16) || pl.igemm, MF_EINVAL,
+             "conv: MF_CONV_FP32_SPLIT3_W3 / MF_CONV_BF16 (converted weights) exist on the implicit-GEMM path only (ask mf_conv2d_is_igemm)");
   MF_REQUIRE(d->C2 == 0 || x2 != nullptr, MF_EINVAL, "conv: C2 > 0 but x2 is null");
   hipStream_t s = (hipStream_t)stream;
   ConvP p;
@@ -1070,7 +1114,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.tiles_m = cdiv(pl.M, pl.cfg.BM);
   p.tiles_n = d->Cout / pl.cfg.BN;
   {
-    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = (d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : 4.0) * d->Cout * pl.K * (p.subpix ? 4 : 1);
+    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = (d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : d->precision == MF_CONV_BF16 ? 2.0 : 4.0) * d->Cout * pl.K * (p.subpix ? 4 : 1);
     MF_REQUIRE(b1 < 4294967040.0 && b2 < 4294967040.0 && bw < 4294967040.0, MF_EUNSUPPORTED,
                "conv: a source tensor exceeds the 4 GiB buffer-descriptor range (shard the batch)");
     p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;
@@ -1094,6 +1138,19 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
         case 9: rc = launch_igemm<128, 256, 2, 4, 32, 2>(p, s); break;
         case 10: rc = launch_igemm<256, 128, 4, 2, 32, 2>(p, s); break;
         default: set_error("conv: tile config %d is not built for the split-bf16 chunk-sum mode", pl.cfg.id); rc = MF_EINVAL;
+      }
+    } else if (d->precision == MF_CONV_BF16) {
+      switch (pl.cfg.id) {
+        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 5>(p, s); break;
+        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 5>(p, s); break;
+        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 5>(p, s); break;
+        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 5>(p, s); break;
+        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 5>(p, s); break;
+        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 5>(p, s); break;
+        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 5>(p, s); break;
+        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 5>(p, s); break;
+        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 5>(p, s); break;
+        default: set_error("conv: tile config %d is not built for the bf16 mode", pl.cfg.id); rc = MF_EINVAL;
       }
     } else if (d->precision == MF_CONV_FP32_SPLIT3_W3) {
       switch (pl.cfg.id) {

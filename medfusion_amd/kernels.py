@@ -95,6 +95,17 @@ def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_lay
     return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, precision)
 
 
+def convert_conv_weight_bf16(w_packed: torch.Tensor) -> torch.Tensor:
+    """packed fp32 weights -> bf16 (round to nearest even) for the opt-in MF_CONV_BF16 mode: opaque int16 tensor [rows, K]"""
+    _gpu(w_packed)
+    w = w_packed.contiguous()
+    k = w.shape[-1] * w.shape[-2] * w.shape[-3]
+    rows = w.numel() // k
+    out = torch.empty((rows, k), dtype=torch.int16, device=w.device)
+    L.check(L.load().mf_convert_conv_weight_bf16(w.data_ptr(), out.data_ptr(), rows, k, stream()), "mf_convert_conv_weight_bf16")
+    return out
+
+
 def conv_out_hw(d: L.MfConvDesc):
     up = 1 if d.upsample else 0
     he, we = d.Hin << up, d.Win << up

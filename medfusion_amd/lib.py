@@ -46,6 +46,7 @@ _SIGS = {
     "mf_conv2d_subpixel_ok": (_I, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_is_igemm": (_I, [C.POINTER(MfConvDesc)]),
     "mf_split_conv_weight_bf16x3": (_I, [c_fp, c_fp, C.c_long, _I, c_fp]),
+    "mf_convert_conv_weight_bf16": (_I, [c_fp, c_fp, C.c_long, _I, c_fp]),
     "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),

@@ -130,6 +130,34 @@ def test_conv_presplit_weights_bit_identical(dev, case, tile):
         assert torch.equal(K.conv2d(xd, wp, b.to(dev), d1, x2=x2d), K.conv2d(xd, w3, b.to(dev), d3, x2=x2d)), (case, tile, sk)
 
 
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 4, 8, 9, 10])
+def test_conv_bf16_opt_in_mode(dev, case, tile):
+    """MF_CONV_BF16 (opt-in, reduced precision): the kernel computes EXACTLY conv(bf16(x), bf16(w)) with fp32 accumulation (checked to
+    1e-5 against an fp64 convolution of the rounded operands) -- and is therefore ~3e-3 away from the fp32 result (stated tolerance 2e-2)."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    bn = {1: 128, 4: 64, 8: 128, 9: 256, 10: 128}.get(tile, 32)
+    if tile and co % bn:
+        pytest.skip("tile does not divide Cout")
+    x = _rand(f"cx{case}", (n, c1, h, w))
+    x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"cb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want32 = _conv_ref(x, x2, wt, b, stride, pad, ups)
+    rb = lambda t: None if t is None else t.bfloat16().float()
+    want16 = _conv_ref(rb(x), rb(x2), rb(wt), b, stride, pad, ups)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wb = K.convert_conv_weight_bf16(K.pack_conv_weight(wt.to(dev)))
+    for sk in ([0] if tile == 0 else [0, 1, 3]):
+        d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=4)
+        y = K.nhwc_to_nchw(K.conv2d(xd, wb, b.to(dev), d, x2=x2d))
+        assert relerr(y, want16) < 1e-5, (case, tile, sk)
+        assert relerr(y, want32) < 2e-2, (case, tile, sk)
+
+
 def test_conv_split_bf16x3_wide_dynamic_range(dev):
     """operands spanning 12 orders of magnitude (and exact zeros): the 3-way split is exact at every exponent, so the error
     relative to the fp64 result stays fp32-class per output element's own scale"""

@@ -409,3 +409,32 @@ def test_full_length_cfg2_trajectory_vs_oracle(dev, published, conv_precision):
     print(f"conv precision {conv_precision}: x0 rel-err every 10 iterations:", " ".join(f"{e:.1e}" for e in errs), "| image:", f"{relerr(got, want):.1e}")
     assert max(errs) < TOL
     assert relerr(got, want) < TOL
+
+
+BF16_TOL = 5e-2
+
+
+@torch.no_grad()
+def test_bf16_opt_in_mode_has_its_own_tolerance(dev, published, conv_precision):
+    """MF_CONV_BF16 (opt-in): one UNet evaluation and a 20-iteration trajectory at the published size against the
+    fp32 oracle, with the mode's own tolerance (operands carry 8 significant bits: ~3e-3 per convolution)."""
+    if conv_precision != 1:
+        pytest.skip("runs once")
+    from medfusion_amd import blocks as BLK
+    ora, pipe = published
+    BLK.CONV_PRECISION = 4
+    try:
+        x = S.synth_input("pub256_x", (2, 8, 32, 32))
+        t = torch.tensor([731, 731])
+        want, _ = ora.noise_estimator(x, t, None)
+        got, _ = pipe.noise_estimator(x.to(dev), t.to(dev), None)
+        e_unet = relerr(got, want)
+        ora.set_noise_fn(S.PhiloxNoise(77))
+        tr_o, tr_p = [], []
+        want_img = ora.sample(1, (8, 32, 32), steps=20, use_ddim=True, trace=tr_o)
+        got_img = pipe.sample(1, (8, 32, 32), steps=20, use_ddim=True, noise=oracle_noise(77), trace=tr_p)
+        errs = [relerr(a[0], b[0]) for a, b in zip(tr_p, tr_o)]
+        print(f"bf16 mode: UNet {e_unet:.1e} | x0 along 20 iterations: " + " ".join(f"{e:.1e}" for e in errs[::3]) + f" | image {relerr(got_img, want_img):.1e}")
+        assert e_unet < BF16_TOL and max(errs) < BF16_TOL and relerr(got_img, want_img) < BF16_TOL
+    finally:
+        BLK.CONV_PRECISION = conv_precision
