@@ -111,6 +111,14 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // registers.  The two waves of a SIMD then belong to DIFFERENT workgroups with their own barrier cadence, so one computes while the
   // other sits in its barrier/fragment-read window (with two waves of ONE workgroup per SIMD both sit there at the same time: the
   // matrix pipe was 59 % busy, profiles/r01_pmc_conv_split.csv).
+#ifndef MF_MIDBARRIER
+#define MF_MIDBARRIER 1
+#endif
+  // MB: the double-buffered split modes run with ONE barrier per chunk in the MIDDLE of the MFMA stream: before it a wave stores its
+  // share of chunk k+1 and reads its last fragments of chunk k, after it the first-step fragments of chunk k+1 are prefetched into
+  // the registers the first half of the MFMAs has finished with -- the next chunk's MFMAs start without a barrier and without an
+  // exposed LDS round trip (the barrier window cost ~15 points of matrix-pipe utilisation: profiles/r01_mimic_probe.txt).
+  constexpr bool MB = MF_MIDBARRIER && MODE >= 1 && MODE != 4 && (MODE == 5 ? 1 : 6) * (BM / (WM * 32)) * (BN / (WN * 32)) >= 4;  // >= 8 MFMAs per chunk
   constexpr bool SB = MODE == 4;
   constexpr int NBUF = SB ? 1 : 2;
   // MODE 5 = MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (RNE), one MFMA term, fp32 accumulate; weights
@@ -222,6 +230,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // (a gather running TWO chunks ahead through both sets was built and measured: -1...+1 %, not kept).
   f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
   u32x4 rw0[PW][NP], rw1[PW][NP];
+  bf16x8 fra[2][TM][NP], frb[2][TN][NP];  // split modes: MFMA operand fragments (persist across iterations with the mid barrier)
 
 // (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
 // Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
 #define MF_COMPUTE(SET, KC, DO_STORE, DO_LOAD)                                                                                        \
   {                                                                                                                  \
-    if (!(kAblate & 8)) __syncthreads();                                                                             \
+    if (!MB && !(kAblate & 8)) __syncthreads();                                                                      \
     const float* Ab = Aw + buf * BM * LDK;                                                                           \
     const float* Bb = Bw + buf * BN * LDK;                                                                           \
     if constexpr (MODE == 0) {                                                                                       \
@@ -369,13 +378,16 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     } else { /* two 16-deep MFMA steps per chunk; lane half hf reads the 8 consecutive k [16 s + 8 hf, +8) of each piece.   \
                 The chunk's other work (3-way split + LDS store of chunk k+1, fragment reads of the second step, gather of      \
                 chunk k+3) is cut into small units pinned BETWEEN the MFMAs (sched_barrier fences). */                          \
-      bf16x8 fa[2][TM][NP], fb[2][TN][NP];                                                                             \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                 \
-        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
-          fa[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16));     \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                 \
-        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
-          fb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));     \
+      if constexpr (!MB) {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                             \
+            fra[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16));  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                             \
+            frb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));  \
+      }                                                                                                              \
+      const float* An_ = Aw + (buf ^ 1) * BM * LDK;                                                                  \
+      const float* Bn_ = Bw + (buf ^ 1) * BN * LDK;                                                                  \
       float* sa_ = As + (SB ? 0 : buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                   \
       float* sb_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                   \
       unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
@@ -384,9 +396,11 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
       float* sw_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                         \
-      constexpr int NM = 2 * NTERM * TM * TN, RU = SB ? 0 : TM + TN, UA = SB ? 3 * PA : 3 * (PA - 1);                       \
-      constexpr int UI = RU + UA + (WS ? PW : 3 * PB);  /* double-buffered: A item 0 runs before the MFMAs */        \
-      static_assert(UI <= 8 * NM, "units per MFMA slot");                                                            \
+      constexpr int NM = 2 * NTERM * TM * TN, RU = SB ? 0 : TM + TN, UA = (SB || MB) ? 3 * PA : 3 * (PA - 1);        \
+      constexpr int UB = RU + UA + (WS ? PW : 3 * PB);  /* units before the mid barrier (all of them without one) */ \
+      constexpr int UI = MB ? UB + 1 + RU : UB;                                                                      \
+      constexpr int HS = NM / 2;                                                                                     \
+      static_assert(UB <= 8 * (MB ? HS : NM), "units per MFMA slot");                                                \
       { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
         MF_ADVANCE();                                                                                                \
         const int c0_ = cc * BK;                                                                                     \
@@ -401,12 +415,12 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       if constexpr (SB) { /* all fragments of the chunk into registers, then the buffer is free for chunk k+1 */      \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
           _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
-            fa[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
+            fra[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
           _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
-            fb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
+            frb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
         __syncthreads();                                                                                             \
-      } else {                                                                                                       \
+      } else if constexpr (!MB) {                                                                                    \
         MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
       }                                                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
@@ -419,25 +433,34 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
           if (s_ == 0 && t_ == 0) {                                                                                  \
             f32x16 z_;                                                                                               \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.f;                                              \
-            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], z_, 0, 0, 0); \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], z_, 0, 0, 0); \
           } else {                                                                                                   \
-            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], accc[i_][j_], 0, 0, 0); \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], accc[i_][j_], 0, 0, 0); \
           }                                                                                                          \
         } else {                                                                                                     \
-          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s_][i_][kCA[t_]], fb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
+          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
         }                                                                                                            \
-        { /* the units of slot n: u in [ceil(n UI / NM), ceil((n + 1) UI / NM)), at most two (an inner loop over u stayed    \
-             rolled for the 48-MFMA tiles and sent the fragment arrays to scratch) */                                     \
-          const int ulo_ = (n * UI + NM - 1) / NM, uhi_ = ((n + 1) * UI + NM - 1) / NM;                              \
+        { /* the units of slot n.  Without the mid barrier: UI units spread evenly over the NM slots.  With it: the UB units  \
+             before the barrier over the first half, the barrier after MFMA NM/2 - 1 (the last one that reads the first-step   \
+             fragments), the RU prefetch units over the second half.  (No inner loop over u: it stayed rolled for the 48-MFMA   \
+             tiles and sent the fragment arrays to scratch.) */                                                                \
+          int ulo_, uhi_;                                                                                            \
+          if constexpr (MB) {                                                                                        \
+            if (n < HS) { ulo_ = (n * UB + HS - 1) / HS; uhi_ = ((n + 1) * UB + HS - 1) / HS + (n == HS - 1 ? 1 : 0); } \
+            else { ulo_ = UB + 1 + ((n - HS) * RU + HS - 1) / HS; uhi_ = UB + 1 + ((n - HS + 1) * RU + HS - 1) / HS; } \
+          } else {                                                                                                   \
+            ulo_ = (n * UI + NM - 1) / NM; uhi_ = ((n + 1) * UI + NM - 1) / NM;                                      \
+          }                                                                                                          \
           if (ulo_ < uhi_) { MF_UNIT(ulo_, SET, KC) }                                                                \
           if (ulo_ + 1 < uhi_) { MF_UNIT(ulo_ + 1, SET, KC) }                                                        \
-          if constexpr (UI > 2 * NM) { /* the one-term bf16 mode has few MFMAs: up to 8 units per slot */            \
+          if constexpr (UB > (MB ? HS : NM)) { /* few MFMAs per chunk (4-wave tiles, the one-term bf16 mode): up to 9 units */ \
             if (ulo_ + 2 < uhi_) { MF_UNIT(ulo_ + 2, SET, KC) }                                                      \
             if (ulo_ + 3 < uhi_) { MF_UNIT(ulo_ + 3, SET, KC) }                                                      \
             if (ulo_ + 4 < uhi_) { MF_UNIT(ulo_ + 4, SET, KC) }                                                      \
             if (ulo_ + 5 < uhi_) { MF_UNIT(ulo_ + 5, SET, KC) }                                                      \
             if (ulo_ + 6 < uhi_) { MF_UNIT(ulo_ + 6, SET, KC) }                                                      \
             if (ulo_ + 7 < uhi_) { MF_UNIT(ulo_ + 7, SET, KC) }                                                      \
+            if (ulo_ + 8 < uhi_) { MF_UNIT(ulo_ + 8, SET, KC) }                                                      \
           }                                                                                                          \
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -459,13 +482,24 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       if (kAblate & 16) {                                                                                            \
       } else if (u < TM) {                                                                                           \
         _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
-          fa[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
+          fra[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
       } else {                                                                                                       \
         _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
-          fb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
+          frb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
+      }                                                                                                              \
+    } else if (MB && u == UB) {  /* every wave has stored its share of chunk k+1 and read the last fragments of chunk k */ \
+      if (!(kAblate & 8)) __syncthreads();                                                                           \
+    } else if (MB && u > UB) {   /* first-step fragments of chunk k+1, into the registers MFMA NM/2 - 1 read last */      \
+      const int v_ = u - UB - 1;                                                                                     \
+      if (v_ < TM) {                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                               \
+          fra[0][v_ < TM ? v_ : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(An_ + v_ * 32 * LDK + c * 16)); \
+      } else {                                                                                                       \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                               \
+          frb[0][v_ >= TM && v_ < RU ? v_ - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bn_ + (v_ - TM) * 32 * LDK + c * 16)); \
       }                                                                                                              \
     } else if (u < RU + UA) {                                                                                        \
-      MF_ITEM_A((SB ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                                      \
+      MF_ITEM_A(((SB || MB) ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                              \
     } else if constexpr (WS) {                                                                                       \
       MF_ITEM_W(u - RU - UA, SET)                                                                                    \
     } else {                                                                                                         \
@@ -520,6 +554,17 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
     MF_ADVANCE();
     MF_GLOAD(1, kc_beg + 1);
     MF_LDS_STORE(0, 0);
+    if constexpr (MB) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) fra[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDK + c * 16));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) frb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDK + c * 16));
+    }
   }
 
   int buf = 0;
@@ -1074,7 +1119,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
   p.gn_fin = GnFinal{};
   p.fastg = (p.ups == 0 && (long)d->N * d->Hin * d->Win < (1L << 24) && d->C1 < (1 << 22) && d->C2 < (1 << 22)) ? 1 : 0;
-  if (getenv("MF_CONV_GENERIC_GATHER")) p.fastg = 0;  // A/B switch (scripts, tests)
+  static const bool generic_gather = getenv("MF_CONV_GENERIC_GATHER") != nullptr;  // A/B switch (scripts), read once
+  if (generic_gather) p.fastg = 0;
   const int HWo = pl.Hout * pl.Wout;
   if (gn.stats) {  // last-arriver finalize (gn.counter: zero on entry, zero again on exit)
     if (pl.igemm && pl.splitk == 1)
