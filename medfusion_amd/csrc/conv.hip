@@ -947,6 +947,12 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
       else if (d->Cout % 128 == 0 && pl->M >= 256 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 256)) id = 10;
       else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 3.0 && !(d->upsample == 2 && hw_src % 128)) id = 8;
       else if (d->Cout % 64 == 0) id = 4;
+      // short K and exactly enough 128x128 tiles to fill the chip once: no split-K, no slabs, statistics in the epilogue (4 % faster
+      // than 128x256 + split-K 2 at K = 2304; at K = 4608 the wide tile wins again)
+      if ((id == 9 || id == 10) && pl->K <= 2304 && !(d->upsample == 2 && hw_src % 128)) {
+        const long t8 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
+        if (t8 >= 224 && t8 <= 256) id = 8;
+      }
       // pre-split weights: the single-buffer two-workgroups-per-CU forms win where Cout is too narrow for the 256-wide tile
       // (VAE decoder levels: 128 ch 0.204 vs 0.227 ms, 64 ch 0.269 vs 0.280 ms; profiles/r01_conv_sweep_split.txt)
       if (d->precision == MF_CONV_FP32_SPLIT3_W3 && d->tile_hint == 0) {
