@@ -1,19 +1,25 @@
-// conv.hip -- 2-D convolution for the UNet / VAE of the sampling path, fp32, gfx950.
+// conv.hip -- 2-D convolution for the UNet / VAE of the sampling path, gfx950.  Replaces torch.nn.Conv2d.forward at
+// conv_blocks.py:185,238,66,123-125, unet2.py:259,267, latent_embedders.py:768 (include/medfusion_hip.h has the call-site map).
 //
-//  * conv_igemm_kernel: implicit GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32,
-//    157 TF peak).  M = N*Hout*Wout output pixels, N = Cout, K = KH*KW*Cin ordered (tap, ci).
-//    NHWC activations make every A row of a K-chunk (32 channels of one tap) 128 contiguous bytes;
-//    weights are pre-packed [Cout][KH][KW][Cin] so B rows are contiguous too.  The gather fuses
-//    zero padding, stride 2 (BasicDown), nearest x2 upsampling (BasicUp) and the skip concat
-//    (two source pointers) -- none of those tensors is ever materialised.
-//    LDS tiles are [rows][32+4] floats: both operands are read with ds_read_b128 (4 consecutive k of
-//    one row per lane; lane>>5 selects which 4 of 8), conflict-free with the +4 pad.  The k order
-//    inside a chunk is permuted accordingly (lane half h, sub-step s <-> k = 8*kk + 4*h + s), legal
-//    because A and B use the same permutation.
-//    Register-prefetched double buffering: global loads for chunk k+1 are issued before the MFMAs of
-//    chunk k and written to the other LDS buffer after them; one barrier per chunk.
-//  * split-K (deterministic slabs + reduce kernel) fills the chip when M*Cout is small (8x8, 16x16 levels).
-//  * conv_direct_kernel: any shape / NCHW edges (Cin = 8|3, Cout = 8|3|16): <0.2 % of the FLOPs.
+//  * conv_igemm_kernel<BM,BN,WM,WN,BK,MODE,FG>: implicit GEMM on the matrix cores.  M = N*Hout*Wout output pixels, N = Cout,
+//    K = KH*KW*Cin walked channel-chunk OUTER / filter-tap INNER (L2 locality).  NHWC activations make every A row of a K-chunk
+//    (32 channels of one tap) 128 contiguous bytes; weights are pre-packed [Cout][KH][KW][Cin].  The gather fuses zero padding,
+//    stride 2 (BasicDown), nearest x2 upsampling (BasicUp: gather form or the 4-phase sub-pixel form) and the skip concat (two
+//    source pointers) -- none of those tensors is ever materialised.  Deterministic split-K (slabs + reducer, which also emits the
+//    GroupNorm partial statistics); statistics from the epilogue when K is not split.
+//      MODE 0  MF_CONV_FP32: v_mfma_f32_32x32x2_f32.  LDS tiles [rows][32+4] floats, conflict-free ds_read_b128 (k permuted
+//              identically for A and B), register-prefetched double buffer, one barrier per chunk at the top.
+//      MODE 1  MF_CONV_FP32_SPLIT3: every fp32 operand split exactly into 3 bf16 terms, 6 product terms on
+//              v_mfma_f32_32x32x16_bf16, fp32 accumulate.  LDS rows [3 pieces][32 bf16] + pad.  The chunk's other work is cut into
+//              units pinned between the MFMAs; ONE barrier per chunk in the middle of the MFMA stream, next chunk's first-step
+//              fragments prefetched behind it.
+//      MODE 2  ..._CHUNKSUM: MODE 1 with per-chunk MFMA accumulators added by the VALU.
+//      MODE 3  ..._W3: MODE 1 with the weights already split at load time (the default of the product).
+//      MODE 4  MODE 3 with ONE LDS buffer, fragments held in registers, two 4-wave workgroups per CU (narrow VAE levels).
+//      MODE 5  MF_CONV_BF16: opt-in reduced precision (one bf16 term).
+//    FG: fast gather addressing (no fused nearest-x2 gather, < 2^24 source pixels).
+//  * conv_smallcin_kernel / conv_direct_kernel: the edge convolutions (Cin = 8|3, Cout = 8|3|16, NCHW edges): <0.2 % of the FLOPs.
+//  * DESIGN.md section 3 has the measurements and what was tried and rejected.
 #include "common.h"
 #include "gn_partial.h"
 #include <cstdlib>
