@@ -78,12 +78,17 @@ __global__ __launch_bounds__(512) void mimic(const float* __restrict__ g, float*
           vx[q] = vx[q] - __uint_as_float(b & 0xffff0000u) + 1.0f;
         }
       }
-      if ((F & 4) && n >= 16 && n < 22) {
+      if ((F & 256) && n >= 16 && n < 22) {
+        const int q = n - 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)((blockIdx.x * 512 + tid) * 4 + ((it * 6 + q) & 63) * 8192 * 4 % (1 << 21))),
+                                         (__attribute__((address_space(3))) void*)(lds + 128 * LDK + wave * 256 + q * 2048), 16, 0, 0);
+        *reinterpret_cast<u32x2*>(sw + 64 * LDK + 128 * LDK * (q & 1) + (q >> 1) * 16) = u32x2{rg[q].x, __float_as_uint(vx[q])};
+      } else if ((F & 4) && n >= 16 && n < 22) {
         const int q = n - 16;
         *reinterpret_cast<u32x4*>(sw + 128 * LDK * (q & 1) + (q >> 1) * 16) = rg[q];
         *reinterpret_cast<u32x2*>(sw + 64 * LDK + 128 * LDK * (q & 1) + (q >> 1) * 16) = u32x2{rg[q].x, __float_as_uint(vx[q])};
       }
-      if ((F & 8) && n >= 24 && n < 32) {
+      if ((F & 8) && n >= 24 && n < ((F & 256) ? 26 : 32)) {
         rg[n - 24] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff + (unsigned)((it * 8 + (n - 24)) & 63) * 8192u * 16u % (1u << 23), 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -108,7 +113,7 @@ void run(const float* g, float* out) {
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double per_chunk_ns = ms * 1e6 / iters, ideal_ns = 96 * 32 / 2.0;  // 2 waves per SIMD x 48 MFMAs x 32 cycles at 2.0 GHz
   printf("flags %2d (%s%s%s%s%s%s): %.0f ns per chunk = %.0f %% matrix-pipe busy at 2.0 GHz (%.0f TF bf16)\n", F, F & 1 ? "barrier " : "", F & 2 ? "fragreads " : "",
-         F & 4 ? "ldswrites " : "", F & 8 ? "gloads " : "", F & 16 ? "valu5x12 " : (F & 64 ? "valu2x30 " : ""), F & 128 ? "operands reads1/slot " : (F & 32 ? "operands " : ""), per_chunk_ns, 100.0 * ideal_ns / per_chunk_ns,
+         F & 256 ? "W-by-glds " : (F & 4 ? "ldswrites " : ""), F & 8 ? "gloads " : "", F & 16 ? "valu5x12 " : (F & 64 ? "valu2x30 " : ""), F & 128 ? "operands reads1/slot " : (F & 32 ? "operands " : ""), per_chunk_ns, 100.0 * ideal_ns / per_chunk_ns,
          2.0 * 32 * 32 * 16 * 48 * 8 * 256.0 * iters / (ms * 1e-3) * 1e-12);
 }
 
@@ -116,6 +121,6 @@ int main() {
   float *g, *out;
   (void)hipMalloc(&g, 1u << 25); (void)hipMemset(g, 0, 1u << 25);
   (void)hipMalloc(&out, 256 * 512 * 4);
-  run<32>(g, out); run<48>(g, out); run<96>(g, out); run<34>(g, out); run<162>(g, out); run<63>(g, out); run<111>(g, out); run<239>(g, out); run<238>(g, out);
+  run<32>(g, out); run<111>(g, out); run<367>(g, out); run<110>(g, out); run<366>(g, out);
   return 0;
 }
