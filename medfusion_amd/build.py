@@ -24,7 +24,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gn_partial.h", HERE.parent / "include" / "medfusion_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gn_partial.h", CSRC / "conv_igemm.h", HERE.parent / "include" / "medfusion_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 

@@ -1,0 +1,652 @@
+// conv_igemm.h -- the implicit-GEMM convolution kernel (all arithmetic modes) and its device helpers; included by conv.hip only.
+// See the header of conv.hip for the overview and DESIGN.md section 3 for the measurements behind the choices.
+#pragma once
+#include "common.h"
+#include "gn_partial.h"
+
+using namespace mf;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Timing experiments only (scripts/ablate_split.sh builds side libraries with -DMF_ABLATE=bits; results are then WRONG by design):
+// 1 no split arithmetic, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no second-step fragment reads, 32 no MFMAs,
+// 64 LDS stores of values that do not depend on the global loads (isolates the wait for the loads).
+#ifndef MF_ABLATE
+#define MF_ABLATE 0
+#endif
+constexpr int kAblate = MF_ABLATE;
+
+namespace {
+
+struct ConvP {
+  const float* x1;
+  const float* x2;
+  const float* w;
+  const float* bias;
+  float* y;
+  int N, Hin, Win, C1, C2, Cin, Cout;
+  int Hout, Wout, Heff, Weff;
+  int KH, KW, stride, pad, ups;
+  int M, K, HWout;
+  int cchunks, nk, nk_per_split, splitk;
+  int tiles_m, tiles_n;
+  long slab;
+  int in_nchw, out_nchw;
+  unsigned bytes1, bytes2, bytesw;  // buffer-descriptor extents (igemm path: all < 4 GiB, checked on the host)
+  int subpix, hw_src;               // sub-pixel form of nearest-x2 + 3x3: 4 phase-specific 2x2 convs on the low-res source
+  double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
+  int gn_groups, gn_parts, gn_cpg;
+  GnFinal gn_fin;                   // optional last-arriver finalize -> stats[n][g] = {mean, rstd}
+  int fastg;                        // fast gather usable: no fused nearest-x2 gather, < 2^24 source pixels, < 2^22 channels per source
+};
+
+// bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + within;
+}
+
+// MODE 1 ("fp32 through 3 x bf16"): every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (truncation: h = top
+// 8 significant bits, m = the next 8, l = the last 8), and a*b is accumulated in fp32 on the bf16 matrix cores as the six terms
+// of order <= 2: ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh.  The dropped terms (am*bl, al*bm, al*bl) are < 2^-23 |a*b|, i.e.
+// below fp32 rounding of the product; v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so 6 of them cost 3/8.
+__device__ __forceinline__ void split2_bf16x3(const float x0, const float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned b0 = __float_as_uint(x0), b1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(b0 & 0xffff0000u), r1 = x1 - __uint_as_float(b1 & 0xffff0000u);  // exact
+  const unsigned c0 = __float_as_uint(r0), c1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(c0 & 0xffff0000u), s1 = r1 - __uint_as_float(c1 & 0xffff0000u);  // exact, <= 8 significant bits left
+  // pack the HIGH halves of two words into one: v_perm_b32 (no masking/shift needed)
+  h = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  m = __builtin_amdgcn_perm(c1, c0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned round_bf16x2(const float x0, const float x1) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  const bf16x2 v = {(__bf16)x0, (__bf16)x1};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ u32x2 round_bf16x4(const f32x4 v) {
+  const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  return u32x2{round_bf16x2(x0, x1), round_bf16x2(x2, x3)};
+}
+__device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+  // (scalar copies first: __builtin_bit_cast applied directly to a vector ELEMENT read element 0 every time)
+  const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+  unsigned h0, m0, l0, h1, m1, l1;
+  split2_bf16x3(x0, x1, h0, m0, l0);
+  split2_bf16x3(x2, x3, h1, m1, l1);
+  h = u32x2{h0, h1}; m = u32x2{m0, m1}; l = u32x2{l0, l1};
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
+__global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP p) {
+  constexpr int NT = WM * WN * 64;
+  // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
+  // MODE 1: [3 pieces][32 bf16] = 48 words + 4: pitch/4 = 13 is odd, so the 16 rows of a quarter-wave b128 read hit distinct banks.
+  constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);  // MODE 5: 32 bf16 = 16 words + 4 (pitch/4 = 5, odd)
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
+  // MODE 4 = MODE 3 with ONE LDS buffer and 4-wave workgroups, two of them per CU: the fragments of a chunk are pulled into
+  // registers (barrier | 24 ds_read_b128 | barrier), then the same buffer is refilled with the next chunk while the MFMAs run from
+  // registers.  The two waves of a SIMD then belong to DIFFERENT workgroups with their own barrier cadence, so one computes while the
+  // other sits in its barrier/fragment-read window (with two waves of ONE workgroup per SIMD both sit there at the same time: the
+  // matrix pipe was 59 % busy, profiles/r01_pmc_conv_split.csv).
+#ifndef MF_MIDBARRIER
+#define MF_MIDBARRIER 1
+#endif
+  // MB: the double-buffered split modes run with ONE barrier per chunk in the MIDDLE of the MFMA stream: before it a wave stores its
+  // share of chunk k+1 and reads its last fragments of chunk k, after it the first-step fragments of chunk k+1 are prefetched into
+  // the registers the first half of the MFMAs has finished with -- the next chunk's MFMAs start without a barrier and without an
+  // exposed LDS round trip (the barrier window cost ~15 points of matrix-pipe utilisation: profiles/r01_mimic_probe.txt).
+  constexpr bool MB = MF_MIDBARRIER && MODE >= 1 && MODE != 4 && (MODE == 5 ? 1 : 6) * (BM / (WM * 32)) * (BN / (WN * 32)) >= 4;  // >= 8 MFMAs per chunk
+  constexpr bool SB = MODE == 4;
+  constexpr int NBUF = SB ? 1 : 2;
+  // MODE 5 = MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (RNE), one MFMA term, fp32 accumulate; weights
+  // arrive already converted (mf_convert_conv_weight_bf16).  Same kernel with NP = 1 piece instead of 3.
+  constexpr int NP = MODE == 5 ? 1 : 3, NTERM = MODE == 5 ? 1 : 6;
+  constexpr bool WS = MODE == 3 || MODE == 4 || MODE == 5;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
+  constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
+  constexpr int RPP = NT / TPR;
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/threads mismatch");
+  constexpr int RPW = NT / 4;                 // pre-split weights: 4 threads (8 k each: 3 x 16 bytes) cover one 32-k row
+  constexpr int PW = WS ? BN / RPW : 1;
+  static_assert(!WS || BN % RPW == 0, "tile/threads mismatch (pre-split weights)");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                     // [NBUF][BM][LDK]
+  float* Bs = smem + NBUF * BM * LDK;   // [NBUF][BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int total = p.tiles_m * p.tiles_n * p.splitk;
+  const int logical = xcd_remap(blockIdx.x, total);
+  const int tile_m = logical % p.tiles_m;
+  const int rest = logical / p.tiles_m;
+  const int tile_n = rest % p.tiles_n;
+  const int kz = rest / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc_beg = kz * p.nk_per_split;
+  const int kc_end = min(p.nk, kc_beg + p.nk_per_split);
+
+  const int srow = tid / TPR, skoff = (tid % TPR) * 4;
+
+  // FG ("fast gather", host: no fused nearest-x2 gather, < 2^24 source pixels): per row the pixel index of tap (0,0) and a bit mask
+  // of the taps that fall outside the image; per chunk the gather address is then add + 24-bit mad + bfe + or instead of the
+  // generic coordinate arithmetic (2 compares, 2 full 32-bit multiplies, selects)
+  int a_n[PA], a_iy0[PA], a_ix0[PA], a_pix[PA], a_inv[PA];
+  const unsigned skoff4 = (unsigned)skoff * 4u;
+#pragma unroll
+  for (int q = 0; q < PA; ++q) {
+    const int m = m0 + q * RPP + srow;
+    if (m < p.M) {
+      const int n = m / p.HWout;
+      const int rem = m - n * p.HWout;
+      a_n[q] = n * p.Hin;
+      if (p.subpix) {  // m = (n, phase, y, x) over the SOURCE grid; output pixel (2y + a, 2x + b)
+        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+        const int y = r2 / p.Win, x = r2 - y * p.Win;
+        a_iy0[q] = y + (ph >> 1) - 1;
+        a_ix0[q] = x + (ph & 1) - 1;
+      } else {
+        const int oy = rem / p.Wout;
+        const int ox = rem - oy * p.Wout;
+        a_iy0[q] = oy * p.stride - p.pad;
+        a_ix0[q] = ox * p.stride - p.pad;
+      }
+    } else {
+      a_n[q] = 0;
+      a_iy0[q] = -(1 << 28);  // rows past M: always "out of bounds" -> zeros (address clamps to pixel 0 of image 0)
+      a_ix0[q] = 0;
+    }
+    if constexpr (FG) {
+      unsigned valid = 0;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {  // tap index ty * KW + tx (KH, KW <= 3)
+          const bool in = ty < p.KH && tx < p.KW && (unsigned)(a_iy0[q] + ty) < (unsigned)p.Heff && (unsigned)(a_ix0[q] + tx) < (unsigned)p.Weff;
+          valid |= (in ? 1u : 0u) << (ty * p.KW + tx);
+        }
+      a_inv[q] = (int)~valid;  // bits >= KH*KW stay set: bit 31 is the "chunk past the end" tap
+      a_pix[q] = (a_n[q] + a_iy0[q]) * p.Win + a_ix0[q];
+    } else {
+      a_inv[q] = a_pix[q] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.bytesw, 0x00020000);
+  // sub-pixel form: the tile lies inside one phase (host guarantees hw_src % BM == 0); each phase has its own [Cout][2][2][Cin] weights
+  const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;
+  const unsigned wboff = (unsigned)((phase_t * p.Cout + n0 + srow) * p.K + skoff) * 4u;
+  const int wrow = tid >> 2, wo = tid & 3;
+  const unsigned wsoff = (unsigned)((phase_t * p.Cout + n0 + wrow) * p.K) * (2u * NP) + (unsigned)wo * (16u * NP);  // 2 NP bytes per weight
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // K-chunk order: channel chunk OUTER, filter tap INNER.  The KH*KW taps of one 32-channel chunk read the same 128-byte pixel
+  // segments (shifted by one pixel), so consecutive chunks hit L1/L2; with the taps outside, a whole pass over the channels
+  // (the A footprint of the 32 workgroups of an XCD, > 4 MB L2) lay between two uses of a line and every tap pass missed
+  // (rocprofv3: 50 % L2 hit rate, 7.7x the compulsory bytes fetched).  The weights stay [Cout][tap][Cin]: a chunk is still 128
+  // contiguous bytes per row.
+#ifndef MF_KORDER
+#define MF_KORDER 1
+#endif
+  constexpr bool kTapInner = MF_KORDER == 1;
+  const int taps_ = p.KH * p.KW;
+  int cc = kTapInner ? kc_beg / taps_ : kc_beg % p.cchunks;
+  int tap = kTapInner ? kc_beg - cc * taps_ : kc_beg / p.cchunks;
+  int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  // Two register sets: set 0 holds chunk 0 during the cold start only, set 1 is the steady-state prefetch register set
+  // (a gather running TWO chunks ahead through both sets was built and measured: -1...+1 %, not kept).
+  f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+  u32x4 rw0[PW][NP], rw1[PW][NP];
+  bf16x8 fra[2][TM][NP], frb[2][TN][NP];  // split modes: MFMA operand fragments (persist across iterations with the mid barrier)
+
+// (macros, not lambdas: by-reference captures of the index arrays were demoted to scratch memory)
+// Gather through buffer loads: a descriptor per source tensor, 32-bit byte offsets, and the hardware range check
+// supplies the zero padding (an out-of-range offset returns 0) -- no branch, no select on the data, one basic block.
+// Chunks past the end of this workgroup's K range are "loaded" the same way (all offsets out of range).
+#define MF_GLOAD_SETUP(KC)                                                                                   \
+    const bool lv_ = (KC) < kc_end;                                                                          \
+    const int c0_ = cc * BK;                                                                                 \
+    const bool first_ = c0_ < p.C1;                                                                          \
+    const int Cs_ = first_ ? p.C1 : p.C2;                                                                    \
+    const int coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                   \
+    const int tapoff_ = ky * p.Win + kx, tsel_ = lv_ ? ky * p.KW + kx : 31;                                  \
+    const unsigned Cs4_ = (unsigned)Cs_ * 4u, cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;             \
+    const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+        const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000);
+#define MF_GLOAD_A(SET, Q)                                                                                   \
+  {                                                                                                          \
+    if constexpr (FG) {                                                                                      \
+      const unsigned off = (__umul24((unsigned)(a_pix[Q] + tapoff_), Cs4_) + (cb4_ + skoff4)) |              \
+                           (unsigned)__builtin_amdgcn_sbfe(a_inv[Q], (unsigned)tsel_, 1u);                   \
+      ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 0));         \
+    } else {                                                                                                 \
+      const int iy = a_iy0[Q] + ky, ix = a_ix0[Q] + kx;                                                      \
+      const bool ok = lv_ && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;             \
+      const int sy = iy >> p.ups, sx = ix >> p.ups;                                                          \
+      const unsigned off = (unsigned)(((a_n[Q] + sy) * p.Win + sx) * Cs_ + coff_) * 4u;                      \
+      ra##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? off : 0xFFFFFFF0u, 0, 0)); \
+    }                                                                                                        \
+  }
+#define MF_GLOAD_W(SET, Q)                                                                                   \
+  {  /* one address per row (select + add), the 16-byte pieces through the instruction's immediate offset */  \
+    const unsigned wv_ = lv_ ? wsoff + (unsigned)((Q) * RPW * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * (2u * NP) : 0xFFFFFF00u; \
+    _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                           \
+      rw##SET[Q][c] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wv_ + c * 16u, 0, 0);                       \
+  }
+#define MF_GLOAD_B1(SET, Q)                                                                                  \
+  rb##SET[Q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(                              \
+      rsw, lv_ ? wboff + (unsigned)((Q) * RPP * p.K + (ky * p.KW + kx) * p.Cin + cc * BK) * 4u : 0xFFFFFFF0u, 0, 0));
+#define MF_GLOAD_B(SET, KC)                                                                                  \
+  if constexpr (WS) {                                                                                        \
+    _Pragma("unroll") for (int q = 0; q < PW; ++q) MF_GLOAD_W(SET, q)                                        \
+  } else {                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < PB; ++q) MF_GLOAD_B1(SET, q)                                       \
+  }
+#define MF_GLOAD(SET, KC)                                                                                    \
+  {                                                                                                          \
+    MF_GLOAD_SETUP(KC)                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < PA; ++q) MF_GLOAD_A(SET, q)                                        \
+    MF_GLOAD_B(SET, KC)                                                                                      \
+  }
+#define MF_ADVANCE()                            \
+  {                                             \
+    if (kTapInner) {                            \
+      ++kx;                                     \
+      const int w1_ = (kx == p.KW) ? 1 : 0;     \
+      kx = w1_ ? 0 : kx;                        \
+      ky += w1_;                                \
+      const int w2_ = (ky == p.KH) ? 1 : 0;     \
+      ky = w2_ ? 0 : ky;                        \
+      cc += w2_;                                \
+    } else {                                    \
+      ++cc;                                     \
+      const int w1_ = (cc == p.cchunks) ? 1 : 0; \
+      cc = w1_ ? 0 : cc;                        \
+      kx += w1_;                                \
+      const int w2_ = (kx == p.KW) ? 1 : 0;     \
+      kx = w2_ ? 0 : kx;                        \
+      ky += w2_;                                \
+    }                                           \
+  }
+#define MF_LDS_STORE(BUF, SET)                                                                               \
+  {                                                                                                          \
+    if constexpr (MODE == 0) {                                                                               \
+      float* a_ = As + (BUF) * BM * LDK + srow * LDK + skoff;                                                \
+      float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + skoff;                                                \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) *reinterpret_cast<f32x4*>(a_ + q * RPP * LDK) = ra##SET[q]; \
+      _Pragma("unroll") for (int q = 0; q < PB; ++q) *reinterpret_cast<f32x4*>(b_ + q * RPP * LDK) = rb##SET[q]; \
+    } else { /* 4 consecutive k of one row -> 4 bf16 (8 bytes) in each of the three piece planes of that row */ \
+      float* a_ = As + (BUF) * BM * LDK + srow * LDK + (skoff >> 1);                                         \
+      float* b_ = Bs + (BUF) * BN * LDK + srow * LDK + (skoff >> 1);                                         \
+      _Pragma("unroll") for (int q = 0; q < PA; ++q) {                                                       \
+        if constexpr (NP == 1) {                                                                             \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = round_bf16x4(ra##SET[q]);                          \
+        } else {                                                                                             \
+          u32x2 h_, m_, l_;                                                                                  \
+          split_bf16x3(ra##SET[q], h_, m_, l_);                                                              \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK) = h_;                                                \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 16) = m_;                                           \
+          *reinterpret_cast<u32x2*>(a_ + q * RPP * LDK + 32) = l_;                                           \
+        }                                                                                                    \
+      }                                                                                                      \
+      if constexpr (WS) {                                                                                    \
+        float* w_ = Bs + (BUF) * BN * LDK + wrow * LDK + wo * 4;                                             \
+        _Pragma("unroll") for (int q = 0; q < PW; ++q)                                                       \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                     \
+            *reinterpret_cast<u32x4*>(w_ + q * RPW * LDK + c * 16) = rw##SET[q][c];                          \
+      } else {                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < PB; ++q) {                                                     \
+          u32x2 h_, m_, l_;                                                                                  \
+          split_bf16x3(rb##SET[q], h_, m_, l_);                                                              \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK) = h_;                                                \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 16) = m_;                                           \
+          *reinterpret_cast<u32x2*>(b_ + q * RPP * LDK + 32) = l_;                                           \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+
+  const int frag_off = (lane & 31) * LDK + 4 * (lane >> 5);
+  const float* Aw = As + (wm * TM * 32) * LDK + frag_off;
+  const float* Bw = Bs + (wn * TN * 32) * LDK + frag_off;
+
+  // Pipeline (one barrier per K-chunk, at the TOP of the iteration):
+  //   iteration k:  barrier | fragment reads | LDS-store chunk k+1 (register set (k+1)&1, loaded during iteration k-2) -> buf^1 |
+  //                 issue the global loads of chunk k+3 into the same set | MFMAs of chunk k from buf.
+  // Every iteration stores and loads (chunks past the end are all-out-of-range loads and a store nobody reads): one body, no tail.
+  // Variants that were built, verified and measured SLOWER on MI355X (git history): a ping-pong schedule between
+  // the two waves of each SIMD (fp32 and split mode), BK = 64 for the 8-wave tile.
+  // Hazards: buf^1 was last read in iteration k-1 (all waves are past this iteration's barrier); chunk k in buf was
+  // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
+#define MF_COMPUTE(SET, KC, DO_STORE, DO_LOAD)                                                                                        \
+  {                                                                                                                  \
+    if (!MB && !(kAblate & 8)) __syncthreads();                                                                      \
+    const float* Ab = Aw + buf * BM * LDK;                                                                           \
+    const float* Bb = Bw + buf * BN * LDK;                                                                           \
+    if constexpr (MODE == 0) {                                                                                       \
+      f32x4 fa[2][TM], fb[2][TN];                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);  \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);  \
+      if (DO_STORE) MF_LDS_STORE(buf ^ 1, SET);                                                                      \
+      if (DO_LOAD) { MF_ADVANCE(); MF_GLOAD(SET, KC); }                                                              \
+      _Pragma("unroll") for (int kk = 0; kk < BK / 8; ++kk) {                                                        \
+        const int cur = kk & 1, nxt = cur ^ 1;                                                                       \
+        if (kk + 1 < BK / 8) {                                                                                       \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+              fa[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + (kk + 1) * 8);                        \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+              fb[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + (kk + 1) * 8);                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                           \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);    \
+      }                                                                                                              \
+    } else { /* two 16-deep MFMA steps per chunk; lane half hf reads the 8 consecutive k [16 s + 8 hf, +8) of each piece.   \
+                The chunk's other work (3-way split + LDS store of chunk k+1, fragment reads of the second step, gather of      \
+                chunk k+3) is cut into small units pinned BETWEEN the MFMAs (sched_barrier fences). */                          \
+      if constexpr (!MB) {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                             \
+            fra[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16));  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                             \
+            frb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16));  \
+      }                                                                                                              \
+      const float* An_ = Aw + (buf ^ 1) * BM * LDK;                                                                  \
+      const float* Bn_ = Bw + (buf ^ 1) * BN * LDK;                                                                  \
+      float* sa_ = As + (SB ? 0 : buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                   \
+      float* sb_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                   \
+      unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
+      int coff_ = 0, Cs_ = 0, tapoff_ = 0, tsel_ = 31;                                                               \
+      unsigned Cs4_ = 0, cb4_ = 0;                                                                                   \
+      bool lv_ = false;                                                                                              \
+      __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
+      float* sw_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                         \
+      constexpr int NM = 2 * NTERM * TM * TN, RU = SB ? 0 : TM + TN, UA = (SB || MB) ? 3 * PA : 3 * (PA - 1);        \
+      constexpr int UB = RU + UA + (WS ? PW : 3 * PB);  /* units before the mid barrier (all of them without one) */ \
+      constexpr int UI = MB ? UB + 1 + RU : UB;                                                                      \
+      constexpr int HS = NM / 2;                                                                                     \
+      static_assert(UB <= 8 * (MB ? HS : NM), "units per MFMA slot");                                                \
+      { /* K-chunk advance + descriptor of the chunk to gather (scalar work) */                                      \
+        MF_ADVANCE();                                                                                                \
+        const int c0_ = cc * BK;                                                                                     \
+        const bool first_ = c0_ < p.C1;                                                                              \
+        lv_ = (KC) < kc_end;                                                                                         \
+        Cs_ = first_ ? p.C1 : p.C2;                                                                                  \
+        coff_ = (first_ ? c0_ : c0_ - p.C1) + skoff;                                                                 \
+        tapoff_ = ky * p.Win + kx; tsel_ = lv_ ? ky * p.KW + kx : 31;                                                \
+        Cs4_ = (unsigned)Cs_ * 4u; cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;                                \
+        rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
+      }                                                                                                              \
+      if constexpr (SB) { /* all fragments of the chunk into registers, then the buffer is free for chunk k+1 */      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
+            fra[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
+          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
+            frb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
+        __syncthreads();                                                                                             \
+      } else if constexpr (!MB) {                                                                                    \
+        MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
+      }                                                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      f32x16 accc[TM][TN];                                                                                           \
+      _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
+        constexpr int kCA[6] = {2, 0, 1, 1, 0, 0}, kCB[6] = {0, 2, 1, 0, 1, 0};  /* smallest terms first */         \
+        const int j_ = n % TN, i_ = (n / TN) % TM, t_ = NTERM == 1 ? 5 : (n / (TN * TM)) % 6, s_ = n / (TN * TM * NTERM);                 \
+        if (kAblate & 32) {                                                                                          \
+        } else if (FLUSH) {                                                                                          \
+          if (s_ == 0 && t_ == 0) {                                                                                  \
+            f32x16 z_;                                                                                               \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.f;                                              \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], z_, 0, 0, 0); \
+          } else {                                                                                                   \
+            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], accc[i_][j_], 0, 0, 0); \
+          }                                                                                                          \
+        } else {                                                                                                     \
+          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
+        }                                                                                                            \
+        { /* the units of slot n.  Without the mid barrier: UI units spread evenly over the NM slots.  With it: the UB units  \
+             before the barrier over the first half, the barrier after MFMA NM/2 - 1 (the last one that reads the first-step   \
+             fragments), the RU prefetch units over the second half.  (No inner loop over u: it stayed rolled for the 48-MFMA   \
+             tiles and sent the fragment arrays to scratch.) */                                                                \
+          int ulo_, uhi_;                                                                                            \
+          if constexpr (MB) {                                                                                        \
+            if (n < HS) { ulo_ = (n * UB + HS - 1) / HS; uhi_ = ((n + 1) * UB + HS - 1) / HS + (n == HS - 1 ? 1 : 0); } \
+            else { ulo_ = UB + 1 + ((n - HS) * RU + HS - 1) / HS; uhi_ = UB + 1 + ((n - HS + 1) * RU + HS - 1) / HS; } \
+          } else {                                                                                                   \
+            ulo_ = (n * UI + NM - 1) / NM; uhi_ = ((n + 1) * UI + NM - 1) / NM;                                      \
+          }                                                                                                          \
+          if (ulo_ < uhi_) { MF_UNIT(ulo_, SET, KC) }                                                                \
+          if (ulo_ + 1 < uhi_) { MF_UNIT(ulo_ + 1, SET, KC) }                                                        \
+          if constexpr (UB > (MB ? HS : NM)) { /* few MFMAs per chunk (4-wave tiles, the one-term bf16 mode): up to 9 units */ \
+            if (ulo_ + 2 < uhi_) { MF_UNIT(ulo_ + 2, SET, KC) }                                                      \
+            if (ulo_ + 3 < uhi_) { MF_UNIT(ulo_ + 3, SET, KC) }                                                      \
+            if (ulo_ + 4 < uhi_) { MF_UNIT(ulo_ + 4, SET, KC) }                                                      \
+            if (ulo_ + 5 < uhi_) { MF_UNIT(ulo_ + 5, SET, KC) }                                                      \
+            if (ulo_ + 6 < uhi_) { MF_UNIT(ulo_ + 6, SET, KC) }                                                      \
+            if (ulo_ + 7 < uhi_) { MF_UNIT(ulo_ + 7, SET, KC) }                                                      \
+            if (ulo_ + 8 < uhi_) { MF_UNIT(ulo_ + 8, SET, KC) }                                                      \
+          }                                                                                                          \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+      }                                                                                                              \
+      if (FLUSH) {                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];                            \
+      }                                                                                                              \
+    }                                                                                                                \
+    if (!SB) buf ^= 1;                                                                                               \
+  }
+// work unit U of a split-mode chunk (see MF_COMPUTE): [0, RU) second-step fragment reads of one 32-row sub-tile; then 3 units
+// per staging item (items 1..NI-1).
+#define MF_UNIT(U, SET, KC)                                                                                          \
+  {                                                                                                                  \
+    const int u = (U);                                                                                               \
+    if (u < RU) {                                                                                                    \
+      if (kAblate & 16) {                                                                                            \
+      } else if (u < TM) {                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
+          fra[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
+      } else {                                                                                                       \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
+          frb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
+      }                                                                                                              \
+    } else if (MB && u == UB) {  /* every wave has stored its share of chunk k+1 and read the last fragments of chunk k */ \
+      if (!(kAblate & 8)) __syncthreads();                                                                           \
+    } else if (MB && u > UB) {   /* first-step fragments of chunk k+1, into the registers MFMA NM/2 - 1 read last */      \
+      const int v_ = u - UB - 1;                                                                                     \
+      if (v_ < TM) {                                                                                                 \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                               \
+          fra[0][v_ < TM ? v_ : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(An_ + v_ * 32 * LDK + c * 16)); \
+      } else {                                                                                                       \
+        _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                               \
+          frb[0][v_ >= TM && v_ < RU ? v_ - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bn_ + (v_ - TM) * 32 * LDK + c * 16)); \
+      }                                                                                                              \
+    } else if (u < RU + UA) {                                                                                        \
+      MF_ITEM_A(((SB || MB) ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                              \
+    } else if constexpr (WS) {                                                                                       \
+      MF_ITEM_W(u - RU - UA, SET)                                                                                    \
+    } else {                                                                                                         \
+      MF_ITEM_B((u - RU - UA) / 3, (u - RU - UA) % 3, SET)                                                           \
+    }                                                                                                                \
+  }
+// staging items of the chunk being stored.  PART 0/1: split two floats each into bf16 triplets, PART 2: the three 8-byte LDS
+// writes, then the register is free: gather the same row of the chunk this register set holds next.
+#define MF_SPLIT_PARTS(V, PART, DST)                                                                                 \
+    const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (V);                                  \
+    const float e0_ = v_[0], e1_ = v_[1], e2_ = v_[2], e3_ = v_[3];                                                  \
+    if constexpr (NP == 1) {                                                                                         \
+      if ((PART) == 0) h0_ = round_bf16x2(e0_, e1_);                                                                 \
+      if ((PART) == 1) h1_ = round_bf16x2(e2_, e3_);                                                                 \
+    } else if (kAblate & 1) {                                                                                        \
+      if ((PART) == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
+      if ((PART) == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
+    } else {                                                                                                         \
+      if ((PART) == 0) split2_bf16x3(e0_, e1_, h0_, m0_, l0_);                                                       \
+      if ((PART) == 1) split2_bf16x3(e2_, e3_, h1_, m1_, l1_);                                                       \
+    }                                                                                                                \
+    if ((PART) == 2 && !(kAblate & 2)) {                                                                             \
+      float* d_ = (DST);                                                                                             \
+      *reinterpret_cast<u32x2*>(d_) = u32x2{h0_, h1_};                                                               \
+      if constexpr (NP == 3) {                                                                                       \
+        *reinterpret_cast<u32x2*>(d_ + 16) = u32x2{m0_, m1_};                                                        \
+        *reinterpret_cast<u32x2*>(d_ + 32) = u32x2{l0_, l1_};                                                        \
+      }                                                                                                              \
+    }
+#define MF_ITEM_A(Q, PART, SET)                                                                                      \
+  {                                                                                                                  \
+    const int qa_ = (Q) < PA ? (Q) : 0;                                                                              \
+    MF_SPLIT_PARTS(ra##SET[qa_], PART, sa_ + qa_ * RPP * LDK)                                                        \
+    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_A(SET, qa_)                                                          \
+  }
+#define MF_ITEM_B(Q, PART, SET)                                                                                      \
+  {                                                                                                                  \
+    const int qb_ = (Q) < PB ? (Q) : 0;                                                                              \
+    MF_SPLIT_PARTS(rb##SET[qb_], PART, sb_ + qb_ * RPP * LDK)                                                        \
+    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_B1(SET, qb_)                                                         \
+  }
+#define MF_ITEM_W(Q, SET)                                                                                            \
+  {                                                                                                                  \
+    const int qw_ = (Q) < PW ? (Q) : 0;                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(sw_ + qw_ * RPW * LDK + c * 16) = rw##SET[qw_][c]; \
+    MF_GLOAD_W(SET, qw_)                                                                                             \
+  }
+
+  if (kc_beg < kc_end) {
+    // cold start: chunks 0 and 1 in flight before waiting for either (one memory latency, not two)
+    MF_GLOAD(0, kc_beg);
+    MF_ADVANCE();
+    MF_GLOAD(1, kc_beg + 1);
+    MF_LDS_STORE(0, 0);
+    if constexpr (MB) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) fra[0][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Aw + i * 32 * LDK + c * 16));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int c = 0; c < NP; ++c) frb[0][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bw + j * 32 * LDK + c * 16));
+    }
+  }
+
+  int buf = 0;
+  int kc = kc_beg;
+  if constexpr (MODE == 0) {
+    for (; kc + 2 < kc_end; ++kc) {  // steady state: branch-free body
+      MF_COMPUTE(1, kc + 2, true, true);
+    }
+    for (; kc < kc_end; ++kc) {      // last two chunks: nothing left to load, then nothing left to store
+      if (kc + 1 < kc_end) {
+        MF_COMPUTE(1, kc + 2, true, false);
+      } else {
+        MF_COMPUTE(1, kc + 2, false, false);
+      }
+    }
+  } else {
+    // split modes: ONE body -- every iteration stores and gathers; chunks past the end of this workgroup's K range are
+    // all-out-of-range loads (zeros, no traffic) and a store into the buffer nobody reads any more
+    for (; kc < kc_end; ++kc) {
+      MF_COMPUTE(1, kc + 2, true, true);
+    }
+  }
+
+  // epilogue: D[i][j], lane holds column j = lane&31 and rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
+  const bool add_bias = (p.splitk == 1) && p.bias != nullptr;
+  int* orow_tab = reinterpret_cast<int*>(smem) + 2048;  // past the statistics scratch (WM*BN*2 <= 2048 floats)
+  if (p.subpix) {  // scatter: row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
+    __syncthreads();
+    if (tid < BM) {
+      const int m = m0 + tid;
+      const int n = m / p.HWout, rem = m - n * p.HWout;
+      const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+      const int y = r2 / p.Win, x = r2 - y * p.Win;
+      orow_tab[tid] = (n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+    }
+    __syncthreads();
+  }
+  const bool do_stats = p.gn_partial != nullptr;  // host guarantees splitk == 1 and HWout % BM == 0 (tile within one sample)
+  float cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const float bv = add_bias ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rbase = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        const float v = acc[i][j][r] + bv;
+        if (row < p.M) {
+          const long orow = p.subpix ? orow_tab[row - m0] : row;
+          out[orow * p.Cout + col] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+      }
+    }
+    cs[j] = s1;
+    cq[j] = s2;
+  }
+  if (do_stats) {
+    // fused GroupNorm statistics (conv_blocks.py:186): per-channel sums of this tile -> LDS -> per-group fp64 partials
+    __syncthreads();  // LDS tiles are dead; reuse them: chs[WM][BN][2]
+    float* chs = smem;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = cs[j] + __shfl_xor(cs[j], 32, 64);
+      const float s2 = cq[j] + __shfl_xor(cq[j], 32, 64);
+      if (lane < 32) {
+        float* d = chs + ((wm * BN) + (wn * TN + j) * 32 + lane) * 2;
+        d[0] = s1;
+        d[1] = s2;
+      }
+    }
+    __syncthreads();
+    const int ngl = BN / p.gn_cpg;  // groups covered by this tile
+    if (tid < ngl) {
+      double s = 0, q = 0;
+      for (int w = 0; w < WM; ++w) {
+        const float* d = chs + (w * BN + tid * p.gn_cpg) * 2;
+        for (int c = 0; c < p.gn_cpg; ++c) { s += (double)d[2 * c]; q += (double)d[2 * c + 1]; }
+      }
+      const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
+      double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+    if (p.gn_fin.stats) {
+      __syncthreads();  // chs[] consumed
+      double* red = reinterpret_cast<double*>(smem);  // 2*NT doubles + flag: far below the tile buffers' size
+      gn_arrive_and_finalize(p.gn_fin, p.gn_partial, m0 / p.HWout, p.gn_groups, reinterpret_cast<volatile int*>(red + 2 * NT), red);
+    }
+  }
+}
+
+}  // namespace
