@@ -320,6 +320,10 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
         const long t8 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
         if (t8 >= 224 && t8 <= 256) id = 8;
       }
+      // small M, long K (8x8 level at B = 8): the wide tiles cannot reach 256 workgroups even at split-K 16 -> more, smaller tiles
+      if ((id == 9 || id == 10) && (long)cdiv(pl->M, id == 9 ? 128 : 256) * (d->Cout / (id == 9 ? 256 : 128)) * 16 < 224 &&
+          !(d->upsample == 2 && hw_src % 128))
+        id = 8;
       // pre-split weights: the single-buffer two-workgroups-per-CU forms win where Cout is too narrow for the 256-wide tile
       // (VAE decoder levels: 128 ch 0.204 vs 0.227 ms, 64 ch 0.269 vs 0.280 ms; profiles/r01_conv_sweep_split.txt)
       if (d->precision == MF_CONV_FP32_SPLIT3_W3 && d->tile_hint == 0) {
