@@ -101,6 +101,16 @@ int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w_packed, co
                      size_t workspace_bytes, double* gn_partial, float* gn_stats, int32_t* gn_counter, int G, float eps,
                      const MfConvDesc* d, void* stream);
 
+/* Convolution + the WHOLE block epilogue of conv_blocks.py:185-191,236-240,360-363 when the plan splits K: the split-K reducer keeps
+ * its values in registers, the workgroups of one (sample, channel slice) meet at an arrival counter, finalize mean/rstd and write
+ * out = act(gn(conv) * gamma + beta) + residual + emb -- no un-normalised tensor, no finalize / apply launches.
+ * counters: 2 * N * 8 int32, zero on entry, zero again on exit.  parts as for mf_conv2d_gn_f32. */
+int mf_conv2d_gn_apply_ok(const MfConvDesc* d, int G);
+int mf_conv2d_gn_apply_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* out, void* workspace,
+                           size_t workspace_bytes, double* gn_partial, int32_t* counters, int G, float eps, const float* gamma,
+                           const float* beta, const float* residual, const float* emb, int64_t emb_stride, int act, const MfConvDesc* d,
+                           void* stream);
+
 /* ------------------------------------------------------------------ GroupNorm + Swish + residual + embedding
  * Replaces nn.GroupNorm + MONAI Swish + `out + residual` + `x += emb` at conv_blocks.py:186-191,
  * :236-240, :360-363 (UnetResBlock) / :298-301 (UnetBasicBlock).  NHWC.

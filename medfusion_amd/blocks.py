@@ -87,6 +87,11 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #     MFMA term; its own tolerance).  Read per call: set blocks.CONV_PRECISION or the env var.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
 APPLY_FROM_PARTIALS = bool(int(os.environ.get("MEDFUSION_APPLY_FROM_PARTIALS", "0")))  # GroupNorm finalize inside the apply pass (A/B switch)
+# conv + GroupNorm + Swish + residual + embedding as ONE launch pair where the plan splits K (mf_conv2d_gn_apply_f32: the reducer keeps its
+# values in registers across a per-(sample, slice) meeting point).  Correct and tested, but measured 3.5 % SLOWER end to end than the
+# separate reducer / finalize / apply launches (20.23 vs 20.96 images/s, same session): all workgroups of a domain wait for its slowest
+# before any of them applies, and the three small kernels each run at full width.  Off; kept as an A/B switch.
+FUSED_GN_EPILOGUE = bool(int(os.environ.get("MEDFUSION_FUSED_GN_EPILOGUE", "0")))
 PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
 
 
@@ -153,6 +158,43 @@ class Conv(nn.Module):
         return y, K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
 
 
+def _conv_forward_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, in_layout=L.LAYOUT_NHWC):
+    """conv -> GroupNorm -> act -> + residual -> + emb in one launch pair, or None when this convolution cannot (no split-K plan, ...)."""
+    if not FUSED_GN_EPILOGUE or in_layout != L.LAYOUT_NHWC:
+        return None
+    x1, x2 = _split(x)
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    if c1 + c2 != self.in_ch:
+        raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
+    G = norm.num_groups
+    key = ("gn_apply", n, h, w, c1, c2, G, CONV_PRECISION, PRESPLIT_WEIGHTS)
+    ent = self._descs.get(key)
+    if ent is None:
+        d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, self.upsample, precision=CONV_PRECISION)
+        if self.upsample and SUBPIXEL_UPSAMPLE:
+            d2 = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2, precision=CONV_PRECISION)
+            if K.subpixel_ok(d2):
+                d = d2
+        if d.precision == 1 and PRESPLIT_WEIGHTS and K.conv_is_igemm(d):
+            d.precision = 3
+        if d.precision == 4 and not K.conv_is_igemm(d):
+            d.precision = 0
+        ok = K.conv_gn_apply_ok(d, G)
+        ent = (d, K.conv_gn_parts(d, G) if ok else 0, ok)
+        self._descs[key] = ent
+    d, parts, ok = ent
+    if not ok:
+        return None
+    pk = self._packed_sub if d.upsample == 2 else self._packed
+    wp = pk.get_split(self.weight) if d.precision == 3 else pk.get_bf16(self.weight) if d.precision == 4 else pk.get(self.weight)
+    return K.conv2d_gn_apply(x1, wp, self.bias, d, G, parts, norm.weight, norm.bias, x2=x2, eps=norm.eps, act=act, residual=residual, emb=emb,
+                             emb_stride=emb_stride)
+
+
+Conv.forward_gn_apply = _conv_forward_gn_apply
+
+
 class GroupNorm(nn.Module):
     """nn.GroupNorm parameter holder (keys weight/bias)."""
 
@@ -191,6 +233,9 @@ class BasicBlock(nn.Module):
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
+            y = self.conv.forward_gn_apply(x, self.norm, int(self.has_act), residual, emb, emb_stride, in_layout)
+            if y is not None:
+                return y
             return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride)
         y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         if not (self.has_act or residual is not None or emb is not None):

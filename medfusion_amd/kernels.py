@@ -167,6 +167,28 @@ def conv2d_gn(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     return out, stats, partial
 
 
+def conv_gn_apply_ok(d: L.MfConvDesc, G: int) -> bool:
+    return bool(L.load().mf_conv2d_gn_apply_ok(C.byref(d), G))
+
+
+def conv2d_gn_apply(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, G: int, parts: int, gamma, beta,
+                    x2: Optional[torch.Tensor] = None, eps: float = 1e-5, act: int = 1, residual: Optional[torch.Tensor] = None,
+                    emb: Optional[torch.Tensor] = None, emb_stride: int = 0) -> torch.Tensor:
+    """conv -> GroupNorm -> (Swish) -> + residual -> + emb as ONE launch pair (split-K conv + fused reducer/finalize/apply)."""
+    _gpu(x1, x2, w_packed, bias, gamma, beta, residual, emb)
+    lib = L.load()
+    ho, wo = conv_out_hw(d)
+    out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
+    partial = torch.empty((d.N, parts, G, 2), dtype=torch.float64, device=x1.device)
+    counters = _gn_counter(x1.device, 2 * 8 * d.N)
+    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
+    ws = Workspace.get(need, x1.device)
+    rc = lib.mf_conv2d_gn_apply_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(),
+                                    counters.data_ptr(), G, eps, _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, act, C.byref(d), stream())
+    L.check(rc, "mf_conv2d_gn_apply_f32")
+    return out
+
+
 def gn_stats_fused(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
     """x NHWC -> stats [N,G,2] in ONE launch (partial sums + last-arriver finalize)."""
     _gpu(x)

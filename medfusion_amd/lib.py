@@ -50,6 +50,8 @@ _SIGS = {
     "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_conv2d_gn_apply_ok": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_conv2d_gn_apply_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, c_fp, c_fp, _I, _F, c_fp, c_fp, c_fp, c_fp, _I64, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_gn_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _SZ, c_fp, c_fp, c_fp, _I, _F, C.POINTER(MfConvDesc), c_fp]),
     "mf_gn_stats_fused_f32": (_I, [c_fp, c_fp, c_fp, c_fp, _I, _I, _I, _I, _F, c_fp]),
     "mf_gn_partial_parts": (_I, [_I]),

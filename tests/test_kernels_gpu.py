@@ -540,3 +540,37 @@ def test_image_egress_uint8(dev):
     r = torch.stack([(b.clamp(min=float(b.min()), max=float(b.max())) - b.min()) / max(float(b.max() - b.min()), 1e-5) for b in r])
     want1 = r.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
     assert torch.equal(got1, want1)
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16, 512, 512), (16, 8, 8, 1024, 1024), (4, 32, 32, 512, 256), (3, 16, 16, 256, 512), (16, 8, 8, 2048, 1024)])
+@pytest.mark.parametrize("prec", [1, 0])
+def test_conv_gn_apply_fused_epilogue(dev, shape, prec):
+    """mf_conv2d_gn_apply_f32 (split-K conv + ONE kernel for reduce / GroupNorm statistics / finalize / norm+Swish+residual+emb, values
+    kept in registers across a per-(sample, slice) meeting point) == the separate conv -> finalize -> apply launches, repeatedly (the
+    arrival counters are self-cleaning)."""
+    from medfusion_amd import kernels as K
+    n, h, w, ci, co = shape
+    G = 32
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((n, h, w, ci), generator=g).to(dev)
+    wt = (torch.randn((co, ci, 3, 3), generator=g) / np.sqrt(9 * ci)).to(dev)
+    b = (torch.randn((co,), generator=g) * 0.1).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn((co,), generator=g)).to(dev), (0.1 * torch.randn((co,), generator=g)).to(dev)
+    res = torch.randn((n, h, w, co), generator=g).to(dev)
+    emb = torch.randn((n, co), generator=g).to(dev)
+    wp = K.pack_conv_weight(wt)
+    d = K.make_conv_desc(n, h, w, ci, 0, co, 3, 1, 1, 0, precision=3 if prec else 0)
+    wk = K.split_conv_weight(wp) if prec else wp
+    if not K.conv_gn_apply_ok(d, G):
+        pytest.skip("this plan does not split K")
+    parts = K.conv_gn_parts(d, G)
+    y, stats, partial = K.conv2d_gn(x, wk, b, d, G, parts, finalize=False)
+    stats = K.gn_finalize(partial, parts, h * w, co, G, 1e-5)
+    want = K.gn_apply(y, stats, gamma, beta, G, 1, res, emb, emb.stride(0))
+    for _ in range(3):
+        got = K.conv2d_gn_apply(x, wk, b, d, G, parts, gamma, beta, eps=1e-5, act=1, residual=res, emb=emb, emb_stride=emb.stride(0))
+        assert bool(torch.isfinite(got).all())
+        assert relerr(got, want) < 2e-6
+    got2 = K.conv2d_gn_apply(x, wk, b, d, G, parts, None, None, eps=1e-5, act=0)   # no affine, no act, no residual, no emb
+    want2 = K.gn_apply(y, stats, None, None, G, 0)
+    assert relerr(got2, want2) < 2e-6
