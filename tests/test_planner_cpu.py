@@ -61,3 +61,52 @@ def test_precision_enum_matches_header():
     assert m and [int(v) for v in m.groups()] == [0, 1, 2, 3, 4]
     from medfusion_amd import blocks as BLK
     assert BLK.CONV_PRECISION in (0, 1, 2)  # the reduced-precision mode (4) is never a default
+
+
+def test_planner_properties_over_many_descriptors():
+    """randomised sweep of the planner through the C-ABI (host only): igemm eligibility follows the documented channel rule, the
+    split-K workspace is a whole number of output slabs, the sub-pixel form implies the implicit-GEMM path, and the fused-epilogue
+    predicate implies a split-K plan that can emit GroupNorm partials."""
+    import random
+    lib = L.load()
+    rnd = random.Random(1234)
+    seen_split = seen_fused = 0
+    for _ in range(400):
+        n = rnd.choice([1, 2, 3, 8, 16])
+        h = rnd.choice([4, 8, 9, 16, 32, 64])
+        w = rnd.choice([4, 8, 12, 16, 32, 64])
+        c1 = rnd.choice([8, 32, 48, 64, 128, 256, 512, 1024])
+        c2 = rnd.choice([0, 0, 32, 256, 512])
+        co = rnd.choice([8, 32, 64, 96, 128, 256, 512, 1024])
+        k = rnd.choice([1, 3])
+        stride = rnd.choice([1, 1, 2])
+        ups = rnd.choice([0, 0, 1, 2]) if (k == 3 and stride == 1) else 0
+        prec = rnd.choice([0, 1, 2, 3, 4])
+        d = _d(n, h, w, c1, c2, co, k=k, stride=stride, ups=ups, prec=prec)
+        ig = lib.mf_conv2d_is_igemm(C.byref(d))
+        rule = c1 % 32 == 0 and c2 % 32 == 0 and co % 32 == 0
+        if ups == 2 and not (rule and (h * w) % 64 == 0):
+            assert ig == 0                      # the sub-pixel form is refused -> the caller falls back to upsample = 1
+            assert lib.mf_conv2d_subpixel_ok(C.byref(d)) == 0
+            continue
+        assert ig == (1 if rule else 0), (n, h, w, c1, c2, co, k, stride, ups, prec)
+        if ups == 2:
+            assert lib.mf_conv2d_subpixel_ok(C.byref(d)) == ig
+        up = 1 if ups else 0
+        ho = ((h << up) + 2 * (1 if k == 3 else 0) - k) // stride + 1
+        wo = ((w << up) + 2 * (1 if k == 3 else 0) - k) // stride + 1
+        ws = lib.mf_conv2d_workspace_bytes(C.byref(d))
+        out_bytes = n * ho * wo * co * 4
+        assert ws % out_bytes == 0
+        sk = ws // out_bytes
+        assert sk == 0 or (ig and 2 <= sk <= 16)
+        seen_split += sk > 0
+        for G in (8, 32):
+            if co % G:
+                continue
+            parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
+            assert parts >= 0 and (ig or parts == 0)
+            if lib.mf_conv2d_gn_apply_ok(C.byref(d), G):
+                assert sk >= 2 and parts > 0
+                seen_fused += 1
+    assert seen_split > 20 and seen_fused > 10   # the sweep does exercise those branches
