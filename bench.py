@@ -2,10 +2,13 @@
 """bench.py -- images/sec of DiffusionPipeline.sample() on MI355X (BASELINE.json metric).
 
 One "step" = one full `sample()` of the workload: cfg2 = 16 images per GPU, latent (8,32,32) -> 256x256,
-150 DDIM iterations (eta=1), unconditional, published architecture (UNet 194 M params + VAE), fp32, synthetic
-seeded weights, device Philox noise, VAE decode and the image all-gather INCLUDED; weights resident in HBM.
-N>1: one process per GPU (torch.distributed.run), batch rows sharded (weak scaling: 16 images per GPU),
-no collective in the loop, one RCCL all-gather of the images per step.
+150 DDIM iterations (eta=1), unconditional, published architecture (UNet 194 M params + VAE), fp32, seeded
+weights, device Philox noise generated inside the timed region, VAE decode and the image all-gather INCLUDED;
+weights resident in HBM.
+N>1: one process per GPU, batch rows sharded (weak scaling: 16 images per GPU), no collective in the loop, one
+RCCL all-gather of the images per step.  `python bench.py --gpus N` launches its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) when it is not already
+running under a launcher, and fails loudly when fewer than N devices are visible.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -13,6 +16,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -22,9 +27,9 @@ sys.path.insert(0, str(ROOT))
 
 import torch
 
-PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
-PEAK_BF16_TFLOPS = 16 * 157.3      # dense bf16 MFMA peak (= 2516.8; "~2.5 PF dense", same guide): the split-mode conv kernel runs on it
-GFLOP_PER_IMAGE_CFG2 = 7743.2     # SURVEY §8d / BASELINE.md: 150 x 51.202 (UNet) + 62.923 (VAE decode)
+PEAK_FP32_TFLOPS = 157.3           # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md): SURVEY §8(d)'s denominator for the ALGORITHMIC flops
+PEAK_MFMA16_TFLOPS = 16 * 157.3    # dense bf16 / fp16 MFMA peak (= 2516.8, "~2.5 PF dense", same guide): what the split-arithmetic kernels EXECUTE on
+GFLOP_PER_IMAGE_CFG2 = 7743.2      # SURVEY §8d / BASELINE.md: 150 x 51.202 (UNet) + 62.923 (VAE decode)
 WORKLOADS = {
     # name: (per-GPU batch, latent, ddim steps, use_ddim, num_classes, guidance)
     "cfg2": dict(batch=16, latent=(8, 32, 32), steps=150, use_ddim=True, classes=None, guidance=1.0),
@@ -33,33 +38,59 @@ WORKLOADS = {
     "cfg4": dict(batch=8, latent=(8, 32, 32), steps=1000, use_ddim=False, classes=None, guidance=1.0),
     "cfg5": dict(batch=8, latent=(8, 64, 64), steps=150, use_ddim=True, classes=None, guidance=1.0),
 }
+ARITH = {
+    0: dict(kernel="conv_igemm_kernel<..., MODE 0>", pmc_match=("conv_igemm_kernel<", ", 0, "), terms=1, peak=PEAK_FP32_TFLOPS, dtype="f32",
+            text="fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain"),
+    1: dict(kernel="conv_igemm_kernel<..., MODE 3>", pmc_match=("conv_igemm_kernel<", ", 3, "), terms=6, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
+            text="fp32 operands split EXACTLY into 3 bf16 terms (24 bits), 6 product terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights "
+                 "pre-split at load"),
+    2: dict(kernel="conv_igemm_kernel<..., MODE 2>", pmc_match=("conv_igemm_kernel<", ", 2, "), terms=6, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
+            text="as 1, per-chunk sums added by the VALU"),
+    4: dict(kernel="conv_igemm_kernel<..., MODE 5>", pmc_match=("conv_igemm_kernel<", ", 5, "), terms=1, peak=PEAK_MFMA16_TFLOPS,
+            dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
+            text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),
+    5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN>", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
+            text="fp32 through PAIRS of fp16: every operand stored as hi + lo/2048 (23 of 24 significand bits, error <= one fp32 ulp, zero for 3 values of 4), 3 product "
+                 "terms on v_mfma_f32_32x32x16_f16, fp32 accumulate; both operands moved HBM->LDS by LDS-DMA (error vs fp64 <= the fp32-MFMA "
+                 "kernel's: tests/test_kernels_gpu.py::test_conv_f16x2)"),
+}
 
 
-def build_pipeline(dev, classes):
-    import medfusion_amd as M
-    from oracle import restate as R   # configs only (kwargs dicts) ...
-    from oracle import synth as S     # ... and the deterministic synthetic weight fill (inputs, not compute)
-    from tests.util import to_product_kwargs
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: become N ranks under torch.distributed.run on this node."""
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {n_vis} ROCm device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
-    from medfusion_amd.utils import no_init
 
-    with no_init():  # every tensor is overwritten by the synthetic fill below
-        pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, M.UNet, None, R.published_scheduler_kwargs(),
-                                   to_product_kwargs(R.published_unet_kwargs(classes)), estimator_objective="x_T", clip_x0=False)
-        pipe.latent_embedder = M.VAE(**R.published_vae_kwargs(8))
-    S.synth_state_dict(pipe.noise_estimator, "published.unet.")
-    S.synth_state_dict(pipe.latent_embedder, "published.vae.")
-    return pipe.to(dev).eval()
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(classes):
-    """The oracle (CPU restatement of the reference, kind='port') on this box's host cores, bounded sample:
-    2 timed UNet forwards at B=4 and 1 VAE decode at B=1 -> extrapolated cfg2 images/s."""
-    from oracle import restate as R
+    """The oracle (CPU restatement of the reference, kind='port') on this box's host cores, bounded sample (SURVEY §8d):
+    3 timed UNet forwards at B=4 and 1 VAE decode at B=1 -> extrapolated cfg2 images/s."""
+    from oracle import restate as R   # the ONLY place bench.py touches oracle/: the CPU leg
     from oracle import synth as S
 
-    cores = min(32, os.cpu_count() or 1)  # ATen's CPU convs scale poorly past ~32 threads (256 threads: 50x slower, measured)
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    threads = min(32, ncpu)  # ATen's CPU convolutions collapse past ~32 threads on this host class (256 threads: 50x slower, measured in round 1)
+    torch.set_num_threads(threads)
     unet = R.UNet(**R.published_unet_kwargs(classes)).eval()
     vae = R.VAE(**R.published_vae_kwargs(8)).eval()
     S.synth_state_dict(unet, "published.unet.")
@@ -69,18 +100,32 @@ def cpu_baseline(classes):
     with torch.no_grad():
         unet(x, t)  # warm-up
         t0 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(3):
             unet(x, t)
-        t_unet = (time.perf_counter() - t0) / 2
+        t_unet = (time.perf_counter() - t0) / 3
         z = x[:1]
         vae.decode(z)
         t0 = time.perf_counter()
         vae.decode(z)
         t_dec = time.perf_counter() - t0
     ips = 4.0 / (150 * t_unet + 4 * t_dec)
-    return {"value": round(ips, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement, torch fp32, {cores} threads): 2 UNet forwards at B=4 ({t_unet:.3f} s each) + 1 VAE decode at B=1 "
-                      f"({t_dec:.3f} s), extrapolated to 150 steps"}
+    return {"value": round(ips, 5), "unit": "images/s", "cores": threads, "host_logical_cpus": ncpu, "cpu_model": cpu_model(), "kind": "port",
+            "sample": f"oracle (CPU restatement of the reference, torch fp32, {threads} threads of {ncpu} logical CPUs): 3 UNet forwards at B=4 "
+                      f"({t_unet:.3f} s each) + 1 VAE decode at B=1 ({t_dec:.3f} s), extrapolated to 150 iterations x 4 images"}
+
+
+def pmc_traffic(match):
+    """HBM bytes per launch of the most frequent conv tile: PMC counters cannot be read live, so they come from the committed rocprofv3
+    passes over this same command (scripts/pmc_bench_traffic.sh -> profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950)."""
+    try:
+        pj = json.load(open(ROOT / "profiles" / "pmc_bench_traffic.json"))
+        cand = [e for e in pj["kernels"] if all(m in e["kernel"] for m in match)]
+        if cand:
+            top = max(cand, key=lambda e: e.get("launches", 0))
+            return top["hbm_bytes_per_launch"], f"profiles/pmc_bench_traffic.json [{top['kernel'][:80]}]: " + pj["method"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 def main():
@@ -94,23 +139,30 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the denoise iteration as a captured hipGraph (default for cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", type=int, default=None, choices=[0, 1, 2, 4],
-                    help="arithmetic of the conv kernel (MF_CONV_*): 1 = fp32 via exact 3 x bf16 split (default), 0 = fp32 MFMA, 2 = split + chunk sums, "
-                         "4 = opt-in REDUCED precision (bf16 operands): not the headline metric")
-    ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed step on the other conv arithmetic")
+    ap.add_argument("--conv-precision", type=int, default=None, choices=sorted(ARITH),
+                    help="arithmetic of the conv kernel (MF_CONV_*): see ARITH in this file; 4 is the opt-in REDUCED precision mode, never the headline")
+    ap.add_argument("--alt-precision", type=int, default=None, choices=sorted(ARITH), help="also time the same step on this arithmetic (default: the other fp32-class ones)")
+    ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed steps on the other conv arithmetics")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     import medfusion_amd as M
+    from medfusion_amd import blocks as BLK
     from medfusion_amd import dist as D
     from medfusion_amd import kernels as K
+    from medfusion_amd import published as P
     import torch.distributed as dist
 
-    from medfusion_amd import blocks as BLK
     if args.conv_precision is not None:
         BLK.CONV_PRECISION = args.conv_precision
     prec = BLK.CONV_PRECISION
     rank, local, world = D.init_from_env()
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    if torch.cuda.device_count() < (local + 1 if world > 1 else 1):
+        raise SystemExit(f"bench.py: rank {rank} needs device {local}, {torch.cuda.device_count()} visible")
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
     wl = dict(WORKLOADS[args.workload])
@@ -119,7 +171,7 @@ def main():
     if args.ddim_steps:
         wl["steps"] = args.ddim_steps
     B, n_global = wl["batch"], wl["batch"] * world
-    pipe = build_pipeline(dev, wl["classes"])
+    pipe = P.build_published_pipeline(dev, wl["classes"])
     cond = (torch.arange(n_global, device=dev) % wl["classes"]) if wl["classes"] else None
     kw = dict(steps=wl["steps"], use_ddim=wl["use_ddim"])
     if args.graph or args.workload == "cfg4":
@@ -135,71 +187,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(nsteps, seed0=0):
+        fence()
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            img = one_step(seed0 + k)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert img.shape[0] == n_global and bool(torch.isfinite(img).all())
+        return dt
+
     for w in range(args.warmup):
-        img = one_step(1000 + w)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        img = one_step(k)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert img.shape[0] == n_global and bool(torch.isfinite(img).all())
+        one_step(1000 + w)
+    dt = timed(args.steps)
     ips = n_global * args.steps / dt
 
     roof = None
+    ar = ARITH[prec]
     if not args.no_roofline and rank == 0:
-        # live launch timing of the dominant kernel (conv_igemm): one more full step of the SAME workload with every launch
-        # bracketed by hipEvents on its stream (mf_prof_*); rocprofv3 --kernel-trace of this command sees the same mix
+        # live launch timing: one more full step of the SAME workload with every launch bracketed by hipEvents on its stream (mf_prof_*);
+        # rocprofv3 --kernel-trace of this command sees the same mix (profiles/)
         with K.prof() as p:
             pipe.sample(B, wl["latent"], condition=None if cond is None else cond[:B], noise=M.PhiloxDeviceNoise(7), steps=wl["steps"],
                         use_ddim=wl["use_ddim"], **({} if cond is None else dict(guidance_scale=wl["guidance"], un_cond=None)))
         tab = p.table()
-        ms, n, fl, _ = tab["conv_igemm"]
+        ms, n, fl, _, ex = tab["conv_igemm"]
         total_ms = sum(v[0] for v in tab.values())
-        alg = fl / (ms * 1e-3) / 1e12          # algorithmic FLOPs of the reference convolutions / launch time
-        if prec == 0:
-            mode = 0
-            name, peak, executed = "conv_igemm_kernel<MODE 0> (v_mfma_f32_32x32x2_f32 implicit-GEMM conv)", PEAK_FP32_TFLOPS, 1
-        elif prec == 4:
-            mode = 5
-            name, peak, executed = "conv_igemm_kernel<..., MODE 5> (REDUCED precision: operands rounded to bf16, one MFMA term, fp32 accumulate)", PEAK_BF16_TFLOPS, 1
-        else:   # six bf16 MFMA terms per fp32 product: the matrix pipe executes 6x the algorithmic FLOPs
-            mode = 3 if (prec == 1 and BLK.PRESPLIT_WEIGHTS) else prec
-            name, peak, executed = "conv_igemm_kernel<..., MODE %d> (fp32 via exact 3 x bf16 split, v_mfma_f32_32x32x16_bf16, fp32 accumulate%s)" % (
-                mode, "; weights pre-split at load" if mode == 3 else ""), PEAK_BF16_TFLOPS, 6
-        ach = alg * executed
-        traffic, traffic_src = None, None
-        try:  # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live, so they come from the committed
-            # rocprofv3 passes over this same command (scripts/pmc_bench_traffic.sh -> profiles/pmc_bench_traffic.json)
-            pj = json.load(open(Path(__file__).resolve().parent / "profiles" / "pmc_bench_traffic.json"))
-            cand = [e for e in pj["kernels"] if "conv_igemm_kernel" in e["kernel"] and (", %d>" % mode if prec else ", 0>") in e["kernel"]]
-            if cand:
-                traffic = max(cand, key=lambda e: e["total_fetch_KiB_raw"])["hbm_bytes_per_launch"]
-                traffic_src = "profiles/pmc_bench_traffic.json: " + pj["method"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch of the most frequent conv tile",
-                "traffic_source": traffic_src, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
-                "algorithmic_tflops": round(alg, 2), "executed_over_algorithmic": executed,
-                "share_of_gpu_time": round(ms / total_ms, 4),
-                "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])}}
-    alt = None
+        alg = fl / (ms * 1e-3) / 1e12     # algorithmic FLOPs of the reference convolutions / their launch time
+        exe = ex / (ms * 1e-3) / 1e12     # FLOPs the matrix pipe executes: terms per product x the MACs actually done (sub-pixel up-convs: 4/9)
+        traffic, traffic_src = pmc_traffic(ar["pmc_match"])
+        hbm = {}
+        for fam in ("gn_apply", "splitk_reduce", "gn_stats", "sched", "noise"):
+            if fam in tab and tab[fam][0] > 0:
+                hbm[fam] = {"ms": round(tab[fam][0], 3), "launches": int(tab[fam][1]), "algorithmic_GBps": round(tab[fam][3] / (tab[fam][0] * 1e-3) / 1e9, 1)}
+        roof = {"bound": "mfma", "kernel": f"{ar['kernel']} -- {ar['text']}",
+                "achieved": round(exe, 2), "peak": round(ar["peak"], 1), "unit": "TFLOP/s", "frac": round(exe / ar["peak"], 4),
+                "frac_is": "EXECUTED matrix flops of the implicit-GEMM conv kernel / the dense MFMA peak of the pipe it runs on "
+                           f"({ar['terms']} matrix term(s) per product)",
+                "algorithmic_tflops": round(alg, 2),
+                "frac_fp32_peak_algorithmic": round(alg / PEAK_FP32_TFLOPS, 4),
+                "frac_arithmetic_ceiling": round(alg / (ar["peak"] / ar["terms"]), 4),
+                "arithmetic_ceiling_tflops": round(ar["peak"] / ar["terms"], 1),
+                "executed_over_algorithmic": round(ex / fl, 4),
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch of the most frequent conv tile", "traffic_source": traffic_src,
+                "launches": int(n), "avg_launch_ms": round(ms / n, 5), "share_of_gpu_time": round(ms / total_ms, 4),
+                "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])},
+                "hbm_bound_passes": hbm}
+    alts = []
     if not args.no_alt_path and rank == 0 and world == 1:
-        # the same step on the other conv arithmetic, timed the same way (1 warm-up + max(1, steps) runs), for comparison
-        BLK.CONV_PRECISION = 0 if prec in (1, 2) else 1
-        one_step(2000)
-        fence()
-        t1 = time.perf_counter()
-        for k in range(max(1, args.steps)):
-            one_step(k)
-        fence()
-        dta = (time.perf_counter() - t1) / max(1, args.steps)
-        alt = {"conv_precision": BLK.CONV_PRECISION, "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)}
+        # the same step on the other conv arithmetics, timed the same way (1 warm-up + max(1, steps) runs), for comparison
+        others = [args.alt_precision] if args.alt_precision is not None else [a for a in (5, 1, 0) if a != prec][:2]
+        for a in others:
+            BLK.CONV_PRECISION = a
+            one_step(2000)
+            dta = timed(max(1, args.steps)) / max(1, args.steps)
+            alts.append({"conv_precision": a, "arithmetic": ARITH[a]["text"], "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)})
         BLK.CONV_PRECISION = prec
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -211,20 +257,19 @@ def main():
             "metric": "images/sec at 256x256, 150 DDIM steps (DiffusionPipeline.sample incl. VAE decode)",
             "value": round(ips, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)" if prec == 4 else "f32", "conv_arithmetic": {4: "REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32", 0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "fp32 operands split exactly into 3 bf16 terms, 6 product terms on the bf16 MFMA, fp32 accumulate (error vs fp64 <= the fp32-MFMA kernel's: tests/test_kernels_gpu.py)", 2: "as 1, per-chunk sums added by the VALU"}[prec],
+            "dtype": ar["dtype"], "conv_precision": prec, "conv_arithmetic": ar["text"],
             "data": "synthetic (seeded weights of the published architecture, device Philox noise)",
             "config": {"workload": f"{args.workload}: {B} images/GPU, latent {wl['latent']}, {wl['steps']} {'DDIM' if wl['use_ddim'] else 'DDPM'} iterations, "
                                    f"{'uncond' if cond is None else 'cond %d-class g=%s' % (wl['classes'], wl['guidance'])}, decode to {8 * wl['latent'][1]}x{8 * wl['latent'][2]}",
                        "global_batch": n_global, "parallelism": f"dp{world} (batch rows sharded, 1 all-gather of images)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        if alt:
-            out["other_conv_arithmetic"] = alt
+        if alts:
+            out["other_conv_arithmetic"] = alts
         if gflop_img:
             out["whole_path_algorithmic_tflops_per_gpu"] = round(ips / world * gflop_img / 1e3, 2)
-            if prec == 0:
-                out["whole_path_frac_of_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)
-        print(json.dumps(out))
+            out["whole_path_frac_of_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 101 /* 0.1.0 */
+#define MF_VERSION 200 /* 0.2.0 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -71,8 +71,15 @@ typedef struct MfConvDesc {
  *   at load time; the kernel then moves them to LDS without any arithmetic.  Implicit-GEMM path only (mf_conv2d_is_igemm).
  * MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (round to nearest even), one MFMA term, fp32
  *   accumulate; `w_packed` points to weights converted by mf_convert_conv_weight_bf16 ([rows][K] bf16).  Error vs fp64 ~3e-3 per
- *   convolution (2^-9 per operand); never selected by default, has its own tolerance in the tests.  Implicit-GEMM path only. */
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4 };
+ *   convolution (2^-9 per operand); never selected by default, has its own tolerance in the tests.  Implicit-GEMM path only.
+ * MF_CONV_FP32_F16X2: fp32 through PAIRS of fp16 on the fp16 matrix cores.  Every operand -- activations and weights -- lives in HBM
+ *   as x ~ hi + lo/2048 with hi = RN16(x), lo = RN16((x - hi) * 2048): 23 of the 24 significand bits (error <= 2^-23 |x|, one fp32
+ *   ulp at most, zero for 3 values of 4; the format is 4 bytes per element like fp32, groups of 8 channels as [hi x 8][lo x 8]).  a*b is accumulated in
+ *   fp32 as wh*xh + (wh*xl + wl*xh)/2048 -- 3 matrix instructions per product instead of 6, dropped term < 2^-22 |a*b|.  Because the
+ *   operands need no arithmetic in the kernel, both go HBM -> LDS by LDS-DMA.  Entry point mf_conv2d_f16x2 (operands produced by
+ *   mf_split_f16x2, by the `ys` output of a previous convolution, or by the split output of mf_gn_apply_split_f32).  |x| <= 65504. */
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4,
+       MF_CONV_FP32_F16X2 = 5 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],
@@ -89,6 +96,19 @@ size_t mf_conv2d_workspace_bytes(const MfConvDesc* d);
 /* y = conv(x1 (++ x2 on channels), w) + bias.  bias may be NULL.  workspace >= mf_conv2d_workspace_bytes. */
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y,
                   void* workspace, size_t workspace_bytes, const MfConvDesc* d, void* stream);
+
+/* --- MF_CONV_FP32_F16X2 (same reference call sites as mf_conv2d_f32: conv_blocks.py:185,238,66,123-125, unet2.py:259)
+ * mf_split_f16x2: fp32 [.., C] (n elements, n % 8 == 0, innermost extent a multiple of 8) -> the fp16-pair form (n * 4 bytes); used for
+ *   packed weights ([rows][K], either packing) once at load time and for activations no producer kernel has split.
+ * mf_conv2d_f16x2: x1s / x2s / ws in fp16-pair form; y fp32 NHWC; ys optional fp16-pair copy of y (for the next convolution);
+ *   gn_partial optional: statistics of the following GroupNorm(G), [N][parts][G][2] doubles, parts = mf_conv2d_gn_parts(d, G) > 0.
+ *   Split-K plans reduce through `workspace` (mf_conv2d_workspace_bytes) with the reducer emitting y, ys and the statistics.
+ * mf_conv2d_plan_query: the tile id and split-K factor the planner picks for `d` (any precision; 0, 0 = not on the implicit-GEMM path). */
+int mf_conv2d_f16x2_ok(const MfConvDesc* d);
+int mf_split_f16x2(const float* x, void* xs, int64_t n, void* stream);
+int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* ys, void* workspace,
+                    size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream);
+int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
 
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
@@ -136,6 +156,10 @@ int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, fl
  * out may alias x. */
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                     const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream);
+/* the same pass, also writing the fp16-pair form of `out` (operand of a following MF_CONV_FP32_F16X2 convolution; C % 8 == 0) */
+int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+                          const float* emb, int64_t emb_stride, float* out, void* out_split, int N, int HW, int C, int G, int act,
+                          void* stream);
 
 /* ------------------------------------------------------------------ small dense ops
  * mf_linear_f32: y[b*y_stride + o] = sum_i f(x[b*x_stride + i]) * w[o*In + i] + bias[o] (+ y if accumulate);
@@ -253,6 +277,8 @@ int mf_prof_enable(int on);
 int mf_prof_reset(void);
 /* synchronises outstanding events; returns summed ms, launch count, algorithmic flops and bytes of a family */
 int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, double* bytes);
+/* the same plus the flops the hardware EXECUTES for those launches (matrix terms per product x the MACs actually done) */
+int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, double* bytes, double* exec_flops);
 const char* mf_prof_family_name(int family);
 
 #ifdef __cplusplus

@@ -49,6 +49,7 @@ class _Packed:
         self._w = None
         self._w3 = None
         self._wb = None
+        self._wh = None
         self._subpixel = subpixel
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
@@ -60,8 +61,16 @@ class _Packed:
             self._w = K.pack_upconv_weight(w) if self._subpixel else K.pack_conv_weight(w)
             self._w3 = None
             self._wb = None
+            self._wh = None
             self._key = key
         return self._w
+
+    def get_f16x2(self, weight: torch.Tensor) -> torch.Tensor:
+        """the same weights as fp16 pairs (MF_CONV_FP32_F16X2), derived once from the fp32 packing"""
+        wp = self.get(weight)
+        if self._wh is None:
+            self._wh = K.split_f16x2(wp)
+        return self._wh
 
     def get_bf16(self, weight: torch.Tensor) -> torch.Tensor:
         """the same weights rounded to bf16 (opt-in MF_CONV_BF16)"""
@@ -84,8 +93,13 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
 #     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
 #     per-chunk sums added by the VALU (the most accurate of the three);  4: opt-in REDUCED precision (operands rounded to bf16, one
-#     MFMA term; its own tolerance).  Read per call: set blocks.CONV_PRECISION or the env var.
+#     MFMA term; its own tolerance);  5: fp32 through PAIRS of fp16 (23-bit operands, three product terms, both operands moved to LDS
+#     by LDS-DMA; convolutions that are not on that kernel run as 1).  Read per call: set blocks.CONV_PRECISION or the env var.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
+
+
+def f16x2_mode() -> bool:
+    return CONV_PRECISION == 5
 APPLY_FROM_PARTIALS = bool(int(os.environ.get("MEDFUSION_APPLY_FROM_PARTIALS", "0")))  # GroupNorm finalize inside the apply pass (A/B switch)
 # conv + GroupNorm + Swish + residual + embedding as ONE launch pair where the plan splits K (mf_conv2d_gn_apply_f32: the reducer keeps its
 # values in registers across a per-(sample, slice) meeting point).  Correct and tested, but measured 3.5 % SLOWER end to end than the
@@ -107,9 +121,34 @@ class Conv(nn.Module):
         self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
 
+    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, split_out):
+        """MF_CONV_FP32_F16X2, or None when this convolution is not on that kernel"""
+        key = ("f16x2", n, h, w, c1, c2, gn_groups)
+        ent = self._descs.get(key)
+        if ent is None:
+            d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=5)
+            ok = K.conv_f16x2_ok(d)
+            ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok)
+            self._descs[key] = ent
+        d, parts, ok = ent
+        if not ok:
+            return None
+        pk = self._packed_sub if d.upsample == 2 else self._packed
+        wh = pk.get_f16x2(self.weight)
+        if not gn_groups:
+            return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, split_out=split_out)
+        ho, wo = K.conv_out_hw(d)
+        if parts > 0:
+            y, partial = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, gn_groups=gn_groups, gn_parts=parts)
+        else:
+            y = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out)
+            partial, parts = K.gn_stats_partial(y, gn_groups)
+        return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)
+
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
-                gn_eps: float = 1e-5):
-        """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2])."""
+                gn_eps: float = 1e-5, split_out: bool = False):
+        """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2]).
+        split_out: in the fp16-pair mode, also emit the fp16-pair mirror of y (the output feeds another convolution directly)."""
         x1, x2 = _split(x)
         if in_layout == L.LAYOUT_NCHW:
             n, c1, h, w = x1.shape
@@ -118,13 +157,20 @@ class Conv(nn.Module):
         c2 = 0 if x2 is None else x2.shape[-1]
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
-        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, CONV_PRECISION, PRESPLIT_WEIGHTS)
+        prec = CONV_PRECISION
+        if prec == 5:
+            if rows is None and in_layout == L.LAYOUT_NHWC and out_layout == L.LAYOUT_NHWC:
+                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, split_out)
+                if r is not None:
+                    return r
+            prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, prec, PRESPLIT_WEIGHTS)
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
-            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout, precision=CONV_PRECISION)
+            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout, precision=prec)
             if self.upsample and SUBPIXEL_UPSAMPLE and rows is None:
-                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=CONV_PRECISION)
+                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=prec)
                 if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
                     d = d2
             if d.precision == 1 and PRESPLIT_WEIGHTS and rows is None and K.conv_is_igemm(d):
@@ -255,7 +301,7 @@ def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
     nm = self.norm
     if isinstance(stats, tuple):  # ("partial", records, parts, eps): finalize inside the apply pass
         return K.gn_apply_partial(y, stats[1], stats[2], nm.weight, nm.bias, nm.num_groups, stats[3], int(self.has_act), residual, emb, emb_stride, out=y)
-    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y)
+    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=f16x2_mode())
 
 
 BasicBlock.conv_and_stats = _basicblock_conv_and_stats
@@ -367,7 +413,7 @@ class BasicDown(nn.Module):
         self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
 
     def forward(self, x, emb=None):
-        return self.down_op(x)
+        return self.down_op(x, split_out=f16x2_mode())
 
 
 class BasicUp(nn.Module):
@@ -382,7 +428,7 @@ class BasicUp(nn.Module):
         self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
 
     def forward(self, x, emb=None):
-        return self.up_op(x)
+        return self.up_op(x, split_out=f16x2_mode())
 
 
 class SequentialEmb(nn.Sequential):

@@ -1,16 +1,24 @@
-"""Builds libmedfusion_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libmedfusion_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One object per source (compiled in parallel, rebuilt only when the source or a header changed), then one link.
+"""
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
+OBJ = CSRC / "build"
 LIB = HERE / "libmedfusion_hip.so"
-SOURCES = ["api.hip", "conv.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall", "-Wno-unused-function"]
+SOURCES = ["api.hip", "conv.hip", "conv_f16x2.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
+HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_plan.h", "split_f16.h"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall",
+          "-Wno-unused-function"]
+LFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]
 
 
 def hipcc() -> str:
@@ -20,21 +28,40 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def needs_build() -> bool:
-    if not LIB.exists():
+def _deps():
+    return [CSRC / h for h in HEADERS] + [HERE.parent / "include" / "medfusion_hip.h"]
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
         return True
-    t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gn_partial.h", CSRC / "conv_igemm.h", HERE.parent / "include" / "medfusion_hip.h"]
+    t = target.stat().st_mtime
     return any(d.stat().st_mtime > t for d in deps)
+
+
+def needs_build() -> bool:
+    return _stale(LIB, [CSRC / s for s in SOURCES] + _deps())
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB)]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    OBJ.mkdir(exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for src in SOURCES:
+        obj = OBJ / (Path(src).stem + ".o")
+        if force or _stale(obj, [CSRC / src] + _deps()):
+            jobs.append([cc, *CFLAGS, "-c", str(CSRC / src), "-o", str(obj)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([cc, *LFLAGS, *[str(OBJ / (Path(s).stem + ".o")) for s in SOURCES], "-o", str(LIB)])
     return LIB
 
 

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
   int family;
   hipEvent_t a, b;
-  double flops, bytes;
+  double flops, bytes, exec_flops;
 };
 static bool g_prof = false;
 static std::mutex g_mu;
@@ -35,22 +35,22 @@ static hipEvent_t get_event() {
     return e;
   }
   hipEvent_t e;
-  hipEventCreate(&e);
+  (void)hipEventCreate(&e);
   return e;
 }
 
-ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes) : idx(-1), stream(s) {
+ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s) {
   if (!g_prof) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  ProfRec r{family, get_event(), get_event(), flops, bytes};
-  hipEventRecord(r.a, s);
+  ProfRec r{family, get_event(), get_event(), flops, bytes, exec_flops < 0 ? flops : exec_flops};
+  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  hipEventRecord(g_recs[idx].b, stream);
+  (void)hipEventRecord(g_recs[idx].b, stream);
 }
 
 }  // namespace mf
@@ -71,7 +71,7 @@ int mf_prof_enable(int on) {
 int mf_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) {
-    hipEventSynchronize(r.b);
+    (void)hipEventSynchronize(r.b);
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
@@ -80,8 +80,12 @@ int mf_prof_reset(void) {
 }
 
 int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, double* bytes) {
+  return mf_prof_query2(family, ms, launches, flops, bytes, nullptr);
+}
+
+int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, double* bytes, double* exec_flops) {
   std::lock_guard<std::mutex> lk(g_mu);
-  double t = 0, fl = 0, by = 0;
+  double t = 0, fl = 0, by = 0, ex = 0;
   int64_t n = 0;
   for (auto& r : g_recs) {
     if (r.family != family) continue;
@@ -90,16 +94,18 @@ int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, doub
       return MF_ELAUNCH;
     }
     float dt = 0;
-    hipEventElapsedTime(&dt, r.a, r.b);
+    (void)hipEventElapsedTime(&dt, r.a, r.b);
     t += dt;
     fl += r.flops;
     by += r.bytes;
+    ex += r.exec_flops;
     ++n;
   }
   if (ms) *ms = t;
   if (launches) *launches = n;
   if (flops) *flops = fl;
   if (bytes) *bytes = by;
+  if (exec_flops) *exec_flops = ex;
   return MF_OK;
 }
 

@@ -14,7 +14,9 @@ void set_error(const char* fmt, ...);
 
 // launch timing (mf_prof_*): when enabled, brackets a launch with two events on its stream.
 struct ProfScope {
-  ProfScope(int family, hipStream_t s, double flops, double bytes);
+  // flops: ALGORITHMIC flops of the reference op; bytes: its compulsory HBM bytes; exec_flops: flops the hardware executes for it
+  // (e.g. 6 or 3 matrix terms per product, 4/9 of the MACs in the sub-pixel form of nearest-x2 + 3x3); < 0: same as flops
+  ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops = -1.0);
   ~ProfScope();
   int idx;
   hipStream_t stream;

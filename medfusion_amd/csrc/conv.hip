@@ -27,26 +27,9 @@
 using namespace mf;
 
 #include "conv_igemm.h"
+#include "conv_plan.h"
 
 namespace {
-
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
-                                     long n4, int Cout, int splitk, long slab) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const long e = i * 4;
-    float4 s = *reinterpret_cast<const float4*>(slabs + e);
-    for (int z = 1; z < splitk; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * slab + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    if (bias) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + (e % Cout));
-      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    }
-    *reinterpret_cast<float4*>(y + e) = s;
-  }
-}
 
 // one thread per output element; any channel count, either layout at either edge
 template <bool PIXEL_FAST>
@@ -238,43 +221,12 @@ __global__ void convert_weight_bf16_kernel(const float* __restrict__ w, u32x2* _
 }
 
 // ------------------------------------------------------------------ host-side planning
-struct TileCfg { int id, BM, BN, WM, WN, BK; };
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
     {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32}, {10, 256, 128, 4, 2, 32},
     {11, 128, 128, 2, 2, 32}, {12, 64, 128, 2, 2, 32}, {13, 128, 64, 2, 2, 32},  // MF_CONV_FP32_SPLIT3_W3 only: single LDS buffer, two 4-wave workgroups per CU
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
-
-struct Plan {
-  bool igemm;
-  TileCfg cfg;
-  int splitk, nk_per_split;
-  int Hout, Wout, Heff, Weff, M, K;
-};
-
-int fill_geometry(const MfConvDesc* d, Plan* pl) {
-  MF_REQUIRE(d != nullptr, MF_EINVAL, "conv: null desc");
-  MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
-  MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
-  MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
-  MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
-  MF_REQUIRE(d->precision >= 0 && d->precision <= 4, MF_EINVAL, "conv: precision flag %d", d->precision);
-  MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
-  MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
-  MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
-  const int up = d->upsample ? 1 : 0;
-  pl->Heff = d->Hin << up;
-  pl->Weff = d->Win << up;
-  pl->Hout = (pl->Heff + 2 * d->pad - d->KH) / d->stride + 1;
-  pl->Wout = (pl->Weff + 2 * d->pad - d->KW) / d->stride + 1;
-  MF_REQUIRE(pl->Hout > 0 && pl->Wout > 0, MF_EINVAL, "conv: empty output");
-  const long M = (long)d->N * pl->Hout * pl->Wout;
-  MF_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), MF_EUNSUPPORTED, "conv: problem too large");
-  pl->M = (int)M;
-  pl->K = (d->upsample == 2 ? 4 : d->KH * d->KW) * (d->C1 + d->C2);  // sub-pixel form: 2x2 taps per phase
-  return MF_OK;
-}
 
 int make_plan(const MfConvDesc* d, Plan* pl) {
   int rc = fill_geometry(d, pl);
@@ -362,6 +314,7 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   return MF_OK;
 }
 
+
 template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
 int launch_igemm_fg(const ConvP& p, hipStream_t s) {
   constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);
@@ -383,6 +336,17 @@ int launch_igemm(const ConvP& p, hipStream_t s) {
 
 }  // namespace
 
+namespace mf {
+int igemm_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk) {
+  Plan pl;
+  int rc = make_plan(d, &pl);
+  if (rc) return rc;
+  if (tile_id) *tile_id = pl.igemm ? pl.cfg.id : 0;
+  if (splitk) *splitk = pl.igemm ? pl.splitk : 0;
+  return MF_OK;
+}
+}  // namespace mf
+
 extern "C" {
 
 int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int KH, int KW, void* stream) {
@@ -397,6 +361,7 @@ int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int K
 // Number of per-sample partial records the convolution itself can emit for a following GroupNorm with G groups
 // (0: it cannot -- split-K, direct kernels, a tile straddling two samples; use mf_gn_stats_partial_f32 then).
 int mf_conv2d_gn_parts(const MfConvDesc* d, int G) {
+  if (d && d->precision == MF_CONV_FP32_F16X2) return mf::f16x2_gn_parts(d, G);
   Plan pl;
   if (make_plan(d, &pl) != MF_OK || !pl.igemm || G <= 0 || d->Cout % G) return 0;
   const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
@@ -443,6 +408,7 @@ int mf_conv2d_subpixel_ok(const MfConvDesc* d) {
 }
 
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
+  if (d && d->precision == MF_CONV_FP32_F16X2) return mf::f16x2_workspace_bytes(d);
   Plan pl;
   if (make_plan(d, &pl) != MF_OK) return 0;
   if (!pl.igemm || pl.splitk <= 1) return 0;
@@ -494,6 +460,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
                        const GnOut& gn, const MfConvDesc* d, void* stream) {
   double* gn_partial = gn.partial;
   const int G = gn.G;
+  MF_REQUIRE(d && d->precision != MF_CONV_FP32_F16X2, MF_EINVAL, "conv: MF_CONV_FP32_F16X2 takes fp16-pair operands: call mf_conv2d_f16x2");
   Plan pl;
   int rc = make_plan(d, &pl);
   if (rc) return rc;
@@ -571,7 +538,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     p.y = reinterpret_cast<float*>(workspace);
   }
   {
-    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes);
+    const double terms = d->precision == MF_CONV_FP32 || d->precision == MF_CONV_BF16 ? 1.0 : 6.0;
+    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
     if (d->precision == MF_CONV_FP32_SPLIT3_CHUNKSUM) {
       switch (pl.cfg.id) {
         case 1: rc = launch_igemm<128, 128, 2, 2, 32, 2>(p, s); break;
@@ -670,11 +638,12 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     const long n4 = (long)pl.M * d->Cout / 4;
     ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
     const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4,
-                       d->Cout, pl.splitk, p.slab);
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4,
+                       d->Cout, pl.splitk, p.slab, (void*)nullptr);
     return check_launch("splitk_reduce");
   }
   return MF_OK;
 }
+
 
 }  // extern "C"

@@ -1,0 +1,403 @@
+// conv_f16x2.h -- implicit-GEMM convolution on operands that are ALREADY split into fp16 pairs in HBM (MF_CONV_FP32_F16X2).
+// Included by conv.hip only.  DESIGN.md section 3 has the measurements behind the choices.
+//
+// Arithmetic.  Every fp32 value x (activation or weight) is stored as two fp16 numbers  x ~ hi + lo' / 2048,
+//   hi = RN16(x),  lo' = RN16((x - hi) * 2048)   (the subtraction and the scaling are exact)
+// which keeps 23 of the 24 significand bits (|x - hi - lo'/2048| <= 2^-23 |x|, i.e. at most one ulp of the fp32 value, zero for 3 values
+// out of 4).  A product is accumulated in fp32 on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32-MFMA rate) as three terms
+//   main  += wh * xh            cross += wh * xl' + wl' * xh            result = main + cross / 2048
+// the dropped term wl*xl is < 2^-22 |w x|.  Three matrix instructions per product instead of the six of the exact 3 x bf16 split
+// (MF_CONV_FP32_SPLIT3).  Range: |x| <= 65504 (the split clamps), values below 2^-14 keep an absolute accuracy of 2^-36.
+//
+// Data movement.  Both operands go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA: no VGPR staging, no ds_write, no VALU on
+// the data), three LDS stages, one raw s_barrier per 32-channel chunk in the MIDDLE of the chunk's MFMA stream, counted vmcnt so that
+// two chunks stay in flight across the barrier.  A row of a chunk (32 channels of one filter tap) is 128 contiguous bytes in HBM:
+// [4 groups of 8 channels][hi | lo'][8 fp16]; the LDS image is lane-linear per DMA instruction (8 rows x 128 B), and bank conflicts of
+// the ds_read_b128 fragment reads are avoided by permuting the eight 16-byte slots of a row by (row >> 1) & 7 on the SOURCE address,
+// with the same involution on the read (CDNA guide rule 21).  Zero padding, rows past M: out-of-range buffer offsets (the DMA writes 0).
+//
+// Orientation.  The MFMA A operand is the WEIGHT fragment and B the activation fragment, so a lane ends up with 4 CONSECUTIVE output
+// channels of one pixel per accumulator quad: the epilogue goes through LDS with 16-byte writes and leaves as full 128-bit rows
+// (fp32 NHWC and, optionally, the fp16-pair form for the next convolution).
+#pragma once
+#include "common.h"
+#include "split_f16.h"
+
+namespace mfc2 {
+using namespace mf;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct ConvP2 {
+  const void* x1;   // [N][Hin][Win][C1/8][2][8] fp16 pairs
+  const void* x2;   // second source of the fused channel concat, or null
+  const void* w;    // [phases][Cout][taps][Cin/8][2][8] fp16 pairs
+  const float* bias;
+  float* y;         // fp32 NHWC output, or the split-K slabs
+  void* ys;         // optional fp16-pair copy of the output (splitk == 1)
+  int N, Hin, Win, C1, C2, Cin, Cout;
+  int Hout, Wout, Heff, Weff, KH, KW, stride, pad;
+  int M, K, HWout;
+  int cgroups, cg_per_split, splitk;   // 32-channel chunks: total, per split-K slice (a slice holds ALL taps of its chunks)
+  int tiles_m, tiles_n;
+  long slab;
+  unsigned bytes1, bytes2, bytesw;
+  int subpix, hw_src;
+  double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1)
+  int gn_groups, gn_parts, gn_cpg;
+};
+
+__device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; block b runs on XCD b % 8
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, within = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + within;
+}
+
+#define MFC2_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int FM = BM / WM, FN = BN / WN, TM = FM / 32, TN = FN / 32;
+  static_assert(TM >= 1 && TN >= 1 && FM % 32 == 0 && FN % 32 == 0, "per-wave footprint");
+  constexpr int GP = BM / 64, GQ = BN / 64, NL = GP + GQ;   // DMA instructions per wave and chunk (8 rows x 128 B each)
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+  constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
+  constexpr int NM = 3 * TM * TN;                           // MFMAs per 16-deep step
+  constexpr int NR = 2 * (TM + TN);                         // fragment reads per step
+
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int total = p.tiles_m * p.tiles_n * p.splitk;
+  const int logical = xcd_remap2(blockIdx.x, total);
+  const int tile_m = logical % p.tiles_m;
+  const int rest = logical / p.tiles_m;
+  const int tile_n = rest % p.tiles_n;
+  const int kz = rest / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int cg_beg = kz * p.cg_per_split;
+  const int cg_end = min(p.cgroups, cg_beg + p.cg_per_split);
+  const int taps = p.KH * p.KW;
+  const int nit = (cg_end - cg_beg) * taps;
+
+  // ---- DMA addressing.  Instruction i of this wave moves tile rows 8 (wave + 8 i) + (lane >> 3); LDS slot (lane & 7) of a row holds
+  // source slot (lane & 7) ^ key, key = (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7 for every i.
+  const int lrow = lane >> 3;
+  const unsigned slot16 = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);
+  int a_pix[GP], a_inv[GP];
+#pragma unroll
+  for (int i = 0; i < GP; ++i) {
+    const int m = m0 + 8 * (wave + 8 * i) + lrow;
+    int n_ = 0, iy0 = -(1 << 28), ix0 = 0;   // rows past M: every tap "outside"
+    if (m < p.M) {
+      const int n = m / p.HWout;
+      const int rem = m - n * p.HWout;
+      n_ = n * p.Hin;
+      if (p.subpix) {  // m = (n, phase, y, x) over the SOURCE grid; output pixel (2y + a, 2x + b)
+        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+        const int y = r2 / p.Win, x = r2 - y * p.Win;
+        iy0 = y + (ph >> 1) - 1;
+        ix0 = x + (ph & 1) - 1;
+      } else {
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        iy0 = oy * p.stride - p.pad;
+        ix0 = ox * p.stride - p.pad;
+      }
+    }
+    unsigned valid = 0;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const bool in = ty < p.KH && tx < p.KW && (unsigned)(iy0 + ty) < (unsigned)p.Heff && (unsigned)(ix0 + tx) < (unsigned)p.Weff;
+        valid |= (in ? 1u : 0u) << (ty * p.KW + tx);
+      }
+    a_inv[i] = (int)~valid;
+    a_pix[i] = (n_ + iy0) * p.Win + ix0;
+  }
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.bytesw, 0x00020000);
+  const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;   // a tile lies inside one sub-pixel phase (host: hw_src % BM == 0)
+  const unsigned kbytes = (unsigned)p.K * 4u;                       // one weight row: K elements x 2 pieces x 2 bytes
+  const unsigned qv = (unsigned)(phase_t * p.Cout + n0 + 8 * wave + lrow) * kbytes + slot16;
+
+  // load iterator (runs three chunks ahead of the compute)
+  int l_cc = cg_beg, l_ky = 0, l_kx = 0, l_it = 0, l_st = 0;
+  unsigned pbase[GP];
+  unsigned l_cs4 = 0;
+  __amdgpu_buffer_rsrc_t l_rs = rsw;
+
+#define MFC2_CHUNK_SETUP()                                                                                              \
+  {                                                                                                                     \
+    const int c0_ = l_cc * 32;                                                                                          \
+    const bool first_ = c0_ < p.C1;                                                                                     \
+    l_cs4 = (unsigned)(first_ ? p.C1 : p.C2) * 4u;                                                                      \
+    const unsigned cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u + slot16;                                          \
+    l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
+    _Pragma("unroll") for (int i = 0; i < GP; ++i) pbase[i] = (unsigned)a_pix[i] * l_cs4 + cb4_;                        \
+  }
+// DMA instruction U (0 .. NL-1) of the chunk the load iterator points at, into LDS stage l_st
+#define MFC2_LOAD_UNIT(U)                                                                                               \
+  {                                                                                                                     \
+    constexpr int u_ = (U);                                                                                             \
+    if constexpr (u_ < GP) {                                                                                            \
+      const unsigned tapb_ = (unsigned)(l_ky * p.Win + l_kx) * l_cs4;                                                   \
+      const unsigned off_ = (pbase[u_] + tapb_) | (unsigned)__builtin_amdgcn_sbfe(a_inv[u_], (unsigned)(l_ky * p.KW + l_kx), 1u); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + (wave + 8 * u_) * 1024), \
+                                               16, off_, 0, 0, 0);                                                      \
+    } else {                                                                                                            \
+      constexpr int q_ = u_ - GP;                                                                                       \
+      const unsigned so_ = (unsigned)((l_ky * p.KW + l_kx) * p.Cin + l_cc * 32) * 4u + (unsigned)q_ * 64u * kbytes;     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + BM * ROWB + (wave + 8 * q_) * 1024), \
+                                               16, qv, so_, 0, 0);                                                      \
+    }                                                                                                                   \
+  }
+#define MFC2_LOAD_ADVANCE()                  \
+  {                                          \
+    ++l_it;                                  \
+    l_st = l_st == 2 ? 0 : l_st + 1;         \
+    ++l_kx;                                  \
+    if (l_kx == p.KW) { l_kx = 0; ++l_ky; }  \
+    if (l_ky == p.KH) {                      \
+      l_ky = 0;                              \
+      ++l_cc;                                \
+      if (l_it < nit) MFC2_CHUNK_SETUP()     \
+    }                                        \
+  }
+#define MFC2_LOAD_ALL()                                            \
+  {                                                                \
+    MFC2_LOAD_UNIT(0) MFC2_LOAD_UNIT(1)                            \
+    if constexpr (NL > 2) MFC2_LOAD_UNIT(NL > 2 ? 2 : 0)           \
+    if constexpr (NL > 3) MFC2_LOAD_UNIT(NL > 3 ? 3 : 0)           \
+    if constexpr (NL > 4) MFC2_LOAD_UNIT(NL > 4 ? 4 : 0)           \
+    if constexpr (NL > 5) MFC2_LOAD_UNIT(NL > 5 ? 5 : 0)           \
+    if constexpr (NL > 6) MFC2_LOAD_UNIT(NL > 6 ? 6 : 0)           \
+    if constexpr (NL > 7) MFC2_LOAD_UNIT(NL > 7 ? 7 : 0)           \
+  }
+
+  // ---- fragment addressing: lane reads tile row (lane & 31) (+ 32 per sub-tile), 16-byte slot (4 step + 2 (lane >> 5) + piece) ^ key
+  const int fkey = (lane >> 1) & 7, fh = lane >> 5;
+  int foff[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) foff[s][c] = (lane & 31) * ROWB + (((4 * s + 2 * fh + c) ^ fkey) * 16);
+  const int xrow0 = wm * FM * ROWB;               // activation rows of this wave
+  const int wrow0 = BM * ROWB + wn * FN * ROWB;   // weight rows of this wave
+
+  f32x16 accm[TM][TN], accx[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+  f16x8 fx[2][TM][2], fw[2][TN][2];   // [step][sub-tile][piece]
+
+// fragment read U (0 .. NR-1) of step S from the stage at byte offset SB
+#define MFC2_READ_UNIT(S, SB, U)                                                                                        \
+  {                                                                                                                     \
+    constexpr int u_ = (U);                                                                                             \
+    if constexpr (u_ < 2 * TM) {                                                                                        \
+      fx[S][u_ / 2][u_ % 2] = *reinterpret_cast<const f16x8*>(smem + (SB) + xrow0 + (u_ / 2) * 32 * ROWB + foff[S][u_ % 2]); \
+    } else {                                                                                                            \
+      constexpr int v_ = u_ - 2 * TM;                                                                                   \
+      fw[S][v_ / 2][v_ % 2] = *reinterpret_cast<const f16x8*>(smem + (SB) + wrow0 + (v_ / 2) * 32 * ROWB + foff[S][v_ % 2]); \
+    }                                                                                                                   \
+  }
+// MFMA n (0 .. NM-1) of step S: term t outer so that consecutive instructions hit different accumulators
+#define MFC2_MFMA(S, N_)                                                                                                \
+  {                                                                                                                     \
+    constexpr int n_ = (N_);                                                                                            \
+    constexpr int j_ = n_ % TN, i_ = (n_ / TN) % TM, t_ = n_ / (TN * TM);                                               \
+    if constexpr (t_ == 0) accm[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][0], fx[S][i_][0], accm[i_][j_], 0, 0, 0); \
+    if constexpr (t_ == 1) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][0], fx[S][i_][1], accx[i_][j_], 0, 0, 0); \
+    if constexpr (t_ == 2) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][1], fx[S][i_][0], accx[i_][j_], 0, 0, 0); \
+  }
+
+  if (nit > 0) {
+    // ---- prologue: up to three chunks in flight, wait for the first
+    MFC2_CHUNK_SETUP()
+    MFC2_LOAD_ALL()
+    MFC2_LOAD_ADVANCE()
+    if (nit > 1) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
+    if (nit > 2) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
+    if (nit > 2) { MFC2_WAIT_VM(2 * NL); } else if (nit > 1) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    MFC2_READ_UNIT(0, 0, 0) MFC2_READ_UNIT(0, 0, 1) MFC2_READ_UNIT(0, 0, 2) MFC2_READ_UNIT(0, 0, 3)
+    if constexpr (NR > 4) { MFC2_READ_UNIT(0, 0, NR > 4 ? 4 : 0) MFC2_READ_UNIT(0, 0, NR > 4 ? 5 : 0) }
+    if constexpr (NR > 6) { MFC2_READ_UNIT(0, 0, NR > 6 ? 6 : 0) MFC2_READ_UNIT(0, 0, NR > 6 ? 7 : 0) }
+  }
+
+// slot N_ of a step: one MFMA, then the units whose turn it is.  READ units: NR of them, spread over the NM slots; LOAD units (second
+// half of the chunk only): NL of them, spread over the slots after the reads started.
+#define MFC2_SLOT_A(N_, SB)                                                                                             \
+  {                                                                                                                     \
+    MFC2_MFMA(0, N_)                                                                                                    \
+    constexpr int lo_ = ((N_) * NR + NM - 1) / NM, hi_ = (((N_) + 1) * NR + NM - 1) / NM;                               \
+    if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(1, SB, lo_ < NR ? lo_ : 0)                                      \
+    if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(1, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+#define MFC2_SLOT_B(N_, SB, DO_LOAD)                                                                                    \
+  {                                                                                                                     \
+    MFC2_MFMA(1, N_)                                                                                                    \
+    constexpr int lo_ = ((N_) * NR + NM - 1) / NM, hi_ = (((N_) + 1) * NR + NM - 1) / NM;                               \
+    if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(0, SB, lo_ < NR ? lo_ : 0)                                      \
+    if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(0, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
+    constexpr int ll_ = ((N_) * NL + NM - 1) / NM, lh_ = (((N_) + 1) * NL + NM - 1) / NM;                               \
+    if (DO_LOAD) {                                                                                                      \
+      if constexpr (ll_ < lh_ && ll_ < NL) MFC2_LOAD_UNIT(ll_ < NL ? ll_ : 0)                                           \
+      if constexpr (ll_ + 1 < lh_ && ll_ + 1 < NL) MFC2_LOAD_UNIT(ll_ + 1 < NL ? ll_ + 1 : 0)                           \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+  }
+#define MFC2_REP12(M_, ...)                                                                                             \
+  M_(0, __VA_ARGS__) M_(1, __VA_ARGS__) M_(2, __VA_ARGS__)                                                              \
+  if constexpr (NM > 3) { M_(NM > 3 ? 3 : 0, __VA_ARGS__) M_(NM > 3 ? 4 : 0, __VA_ARGS__) M_(NM > 3 ? 5 : 0, __VA_ARGS__) } \
+  if constexpr (NM > 6) { M_(NM > 6 ? 6 : 0, __VA_ARGS__) M_(NM > 6 ? 7 : 0, __VA_ARGS__) M_(NM > 6 ? 8 : 0, __VA_ARGS__)   \
+                          M_(NM > 6 ? 9 : 0, __VA_ARGS__) M_(NM > 6 ? 10 : 0, __VA_ARGS__) M_(NM > 6 ? 11 : 0, __VA_ARGS__) }
+
+  // ---- main loop.  Iteration `it` (LDS stage st):
+  //   first half : MFMAs of k-step 0 (fragments already in registers) | fragment reads of k-step 1 from stage st
+  //   middle     : lgkmcnt(0) (stage st is fully read by this wave), vmcnt (chunk it+1 of this wave has landed), s_barrier
+  //   second half: MFMAs of k-step 1 | fragment reads of k-step 0 of chunk it+1 | DMA of chunk it+3 into stage st
+  int st = 0, it = 0;
+  for (; it + 3 < nit; ++it) {   // steady state: no branches
+    const int sb = st * STAGE;
+    const int sn = (st == 2 ? 0 : st + 1) * STAGE;
+    MFC2_REP12(MFC2_SLOT_A, sb)
+    MFC2_WAIT_LGKM0();
+    MFC2_WAIT_VM(NL);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    MFC2_REP12(MFC2_SLOT_B, sn, true)
+    MFC2_LOAD_ADVANCE()
+    st = st == 2 ? 0 : st + 1;
+  }
+  for (; it < nit; ++it) {       // last three chunks: nothing left to load
+    const int sb = st * STAGE;
+    const int sn = (st == 2 ? 0 : st + 1) * STAGE;
+    MFC2_REP12(MFC2_SLOT_A, sb)
+    MFC2_WAIT_LGKM0();
+    if (it + 2 < nit) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    MFC2_REP12(MFC2_SLOT_B, sn, false)
+    st = st == 2 ? 0 : st + 1;
+  }
+
+  // ---- epilogue.  D[cout][pixel]: lane holds pixel (lane & 31) and couts (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32 x 32 block.
+  // All DMA has landed (the last iterations wait vmcnt(0)); the stages are dead once every wave has left the loop.
+  MFC2_WAIT_LGKM0();
+  __builtin_amdgcn_s_barrier();
+  constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [pixel][FN couts] fp32 (+16 B: conflict-free b128 writes)
+  char* stg = smem + wave * (FM * PITCH);
+  static_assert(8 * FM * PITCH <= 3 * STAGE, "epilogue staging must fit in the pipeline stages");
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv;
+        *reinterpret_cast<f32x4*>(stg + (i * 32 + (lane & 31)) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
+      }
+  MFC2_WAIT_LGKM0();   // wave-private region: no barrier needed between the write and the read-back
+  constexpr int LPR = FN / 8, RPP = 64 / LPR, NPASS = FM / RPP;   // lanes per pixel row (8 couts each), rows per pass
+  const int rr = lane / LPR, c8 = lane % LPR;
+  const int col0 = n0 + wn * FN + c8 * 8;
+  float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (p.splitk == 1 && p.bias) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + col0);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int row = ps * RPP + rr;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32 + 16);
+    v0 += b0;
+    v1 += b1;
+    const int m = m0 + wm * FM + row;
+    if (m < p.M) {
+      long orow = m;
+      if (p.subpix) {  // row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
+        const int n = m / p.HWout, rem = m - n * p.HWout;
+        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+        const int y = r2 / p.Win, x = r2 - y * p.Win;
+        orow = ((long)n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+      }
+      *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0) = v0;
+      *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0 + 4) = v1;
+      if (p.ys) {
+        u32x4 hi, lo;
+        split8_f16(v0, v1, hi, lo);
+        u32x4* d = reinterpret_cast<u32x4*>(p.ys) + (orow * (p.Cout >> 3) + (col0 >> 3)) * 2;
+        d[0] = hi;
+        d[1] = lo;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1 += v0[e] + v1[e];
+        s2 = fmaf(v0[e], v0[e], s2);
+        s2 = fmaf(v1[e], v1[e], s2);
+      }
+    }
+  }
+  if (p.gn_partial) {  // host guarantees splitk == 1, HWout % BM == 0 (tile inside one sample), BN % cpg == 0, cpg % 8 == 0
+    __builtin_amdgcn_s_barrier();   // every wave has finished with its staging region
+    float* red = reinterpret_cast<float*>(smem);   // [8 waves][64 lanes][2]
+    red[(wave * 64 + lane) * 2] = s1;
+    red[(wave * 64 + lane) * 2 + 1] = s2;
+    MFC2_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    const int ngl = BN / p.gn_cpg;
+    if (tid < ngl) {
+      double s = 0, q = 0;
+      const int slots = p.gn_cpg >> 3;
+      for (int k = 0; k < slots; ++k) {
+        const int slot8 = tid * slots + k;
+        const int wn_ = slot8 / LPR, c8_ = slot8 - wn_ * LPR;
+        for (int wm_ = 0; wm_ < WM; ++wm_)
+          for (int r = 0; r < RPP; ++r) {
+            const float* d = red + ((wm_ * WN + wn_) * 64 + r * LPR + c8_) * 2;
+            s += (double)d[0];
+            q += (double)d[1];
+          }
+      }
+      const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
+      double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
+      o[0] = s;
+      o[1] = q;
+    }
+  }
+}
+
+// fp32 NHWC (any tensor whose innermost extent is a multiple of 8) -> fp16 pairs, 8 channels per thread
+__global__ __launch_bounds__(256) void split_act_f16x2_kernel(const float* __restrict__ x, u32x4* __restrict__ out, long octets) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < octets; o += stride) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o * 8), v1 = *reinterpret_cast<const f32x4*>(x + o * 8 + 4);
+    u32x4 hi, lo;
+    split8_f16(v0, v1, hi, lo);
+    out[o * 2] = hi;
+    out[o * 2 + 1] = lo;
+  }
+}
+
+}  // namespace mfc2

@@ -1,0 +1,212 @@
+// conv_f16x2.hip -- MF_CONV_FP32_F16X2: planner, launch and C-ABI of the fp16-pair implicit-GEMM convolution (kernel: conv_f16x2.h).
+// Replaces torch.nn.Conv2d.forward at conv_blocks.py:185,238,66,123-125 and unet2.py:259 (include/medfusion_hip.h has the call-site map).
+#include "common.h"
+#include "gn_partial.h"
+#include "conv_plan.h"
+#include "conv_f16x2.h"
+
+using namespace mf;
+
+namespace {
+
+// ------------------------------------------------------------------ MF_CONV_FP32_F16X2: planning and launch (kernel: conv_f16x2.h)
+struct Tile2 { int id, BM, BN, WM, WN; };
+const Tile2 kTiles2[] = {
+    {31, 128, 256, 2, 4}, {32, 256, 128, 4, 2}, {33, 128, 128, 2, 4}, {34, 128, 128, 4, 2}, {35, 256, 64, 4, 2}, {36, 128, 64, 4, 2}, {37, 64, 256, 1, 8},
+};
+
+struct Plan2 {
+  bool ok;
+  Tile2 t;
+  int splitk, cg_per_split, cgroups, taps;
+  int Hout, Wout, Heff, Weff, M, K;
+};
+
+int make_plan2(const MfConvDesc* d, Plan2* pl) {
+  Plan g;
+  int rc = fill_geometry(d, &g);
+  if (rc) return rc;
+  pl->Hout = g.Hout; pl->Wout = g.Wout; pl->Heff = g.Heff; pl->Weff = g.Weff; pl->M = g.M; pl->K = g.K;
+  const int Cin = d->C1 + d->C2;
+  const int hw_src = d->Hin * d->Win;
+  pl->taps = d->upsample == 2 ? 4 : d->KH * d->KW;
+  pl->cgroups = Cin / 32;
+  pl->splitk = 1;
+  pl->cg_per_split = pl->cgroups;
+  // fp16-pair operands exist for NHWC tensors with 32-channel chunks; the gather is the fast form (tap validity mask + 32-bit byte
+  // offsets); nearest-x2 only in its sub-pixel form
+  pl->ok = d->in_layout == MF_LAYOUT_NHWC && d->out_layout == MF_LAYOUT_NHWC && d->C1 % 32 == 0 && d->C2 % 32 == 0 && d->Cout % 64 == 0 &&
+           d->upsample != 1 && d->tile_hint >= 0 && (double)d->N * d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * 4.0 < 4294967040.0 &&
+           (double)d->Cout * pl->K * 4.0 * (d->upsample == 2 ? 4 : 1) < 4294967040.0;
+  if (!pl->ok) return MF_OK;
+  const Tile2* c = nullptr;
+  if (d->tile_hint > 0) {
+    for (const auto& k : kTiles2) if (k.id == d->tile_hint) c = &k;
+    MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv(f16x2): bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
+  } else {
+    int id;
+    if (d->Cout % 256 == 0 && pl->M >= 128) id = 31;
+    else if (d->Cout % 128 == 0) id = pl->M >= 256 ? 32 : 33;
+    else id = pl->M >= 256 ? 35 : 36;
+    // exactly enough 128x128 tiles for one wave of workgroups and a short K: no split-K, no slabs
+    if ((id == 31 || id == 32) && pl->K <= 2304) {
+      const long t8 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
+      if (t8 >= 224 && t8 <= 256) id = 33;
+    }
+    if (d->upsample == 2) {  // a tile must lie inside one sub-pixel phase
+      if (id == 32 && hw_src % 256) id = 33;
+      if (id == 35 && hw_src % 256) id = 36;
+      if (hw_src % 128 && d->Cout % 256 == 0) id = 37;
+    }
+    for (const auto& k : kTiles2) if (k.id == id) c = &k;
+  }
+  if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
+  pl->t = *c;
+  const long tiles = (long)cdiv(pl->M, c->BM) * (d->Cout / c->BN);
+  int sk = 1;
+  if (d->splitk_hint > 0) {
+    sk = d->splitk_hint;
+  } else {
+    // one workgroup per CU (>= 96 KB of LDS): top the grid up to one wave of 256 workgroups; a slice keeps >= 18 chunk iterations
+    const int min_cg = pl->taps >= 4 ? 2 : 8;
+    while (tiles * sk * 2 <= 256 && pl->cgroups / (sk * 2) >= min_cg && sk < 16) sk *= 2;
+    // the matrix core adds its 16 products and the accumulator with truncation: keep one accumulation chain <= 96 chunks
+    while ((pl->cgroups / sk) * pl->taps > 96 && pl->cgroups / (sk * 2) >= 1 && sk < 32) sk *= 2;
+  }
+  if (sk > pl->cgroups) sk = pl->cgroups;
+  pl->cg_per_split = cdiv(pl->cgroups, sk);
+  pl->splitk = cdiv(pl->cgroups, pl->cg_per_split);
+  return MF_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
+  constexpr size_t lds = 3u * (BM + BN) * 128u;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = p.tiles_m * p.tiles_n * p.splitk;
+  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN>), dim3(grid), dim3(512), lds, s, p);
+  return check_launch("conv_f16x2");
+}
+
+// partial GroupNorm records the f16x2 convolution (or its split-K reducer) emits; 0: it cannot
+int gn_parts2(const MfConvDesc* d, const Plan2& pl, int G) {
+  if (!pl.ok || G <= 0 || d->Cout % G) return 0;
+  const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
+  if (pl.splitk > 1) return stats_lds_bytes(d->Cout / stats_slices(d->N, HW, d->Cout, G)) <= 64 * 1024 ? stats_chunks(HW) : 0;
+  if (HW % pl.t.BM || pl.t.BN % cpg || cpg % 8) return 0;
+  return HW / pl.t.BM;
+}
+
+
+}  // namespace
+
+namespace mf {
+int f16x2_gn_parts(const MfConvDesc* d, int G) {
+  Plan2 p2;
+  return make_plan2(d, &p2) == MF_OK ? gn_parts2(d, p2, G) : 0;
+}
+size_t f16x2_workspace_bytes(const MfConvDesc* d) {
+  Plan2 p2;
+  if (make_plan2(d, &p2) != MF_OK || !p2.ok || p2.splitk <= 1) return 0;
+  return (size_t)p2.splitk * p2.M * d->Cout * sizeof(float);
+}
+}  // namespace mf
+
+extern "C" {
+
+/* ------------------------------------------------------------------ MF_CONV_FP32_F16X2 */
+int mf_conv2d_f16x2_ok(const MfConvDesc* d) {
+  Plan2 pl;
+  return d && d->precision == MF_CONV_FP32_F16X2 && make_plan2(d, &pl) == MF_OK && pl.ok ? 1 : 0;
+}
+
+int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk) {
+  MF_REQUIRE(d, MF_EINVAL, "plan_query: null desc");
+  if (d->precision == MF_CONV_FP32_F16X2) {
+    Plan2 pl;
+    int rc = make_plan2(d, &pl);
+    if (rc) return rc;
+    if (tile_id) *tile_id = pl.ok ? pl.t.id : 0;
+    if (splitk) *splitk = pl.ok ? pl.splitk : 0;
+    return MF_OK;
+  }
+  return igemm_plan_query(d, tile_id, splitk);
+}
+
+int mf_split_f16x2(const float* x, void* xs, int64_t n, void* stream) {
+  MF_REQUIRE(x && xs && n > 0 && n % 8 == 0, MF_EINVAL, "split_f16x2: bad args (n %% 8 == 0)");
+  const long octets = n / 8;
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * n);
+  const int blocks = (int)((octets + 255) / 256 > 8192 ? 8192 : (octets + 255) / 256);
+  hipLaunchKernelGGL(mfc2::split_act_f16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), octets);
+  return check_launch("split_f16x2");
+}
+
+int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* ys, void* workspace,
+                    size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream) {
+  MF_REQUIRE(d && d->precision == MF_CONV_FP32_F16X2, MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2");
+  Plan2 pl;
+  int rc = make_plan2(d, &pl);
+  if (rc) return rc;
+  MF_REQUIRE(pl.ok, MF_EUNSUPPORTED, "conv(f16x2): this shape/layout is not on the fp16-pair path (ask mf_conv2d_f16x2_ok)");
+  MF_REQUIRE(x1s && ws && y, MF_EINVAL, "conv(f16x2): null pointer");
+  MF_REQUIRE(d->C2 == 0 || x2s != nullptr, MF_EINVAL, "conv(f16x2): C2 > 0 but x2 is null");
+  MF_REQUIRE(!gn_partial || gn_parts2(d, pl, G) > 0, MF_EUNSUPPORTED, "conv(f16x2): cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  mfc2::ConvP2 p;
+  p.x1 = x1s; p.x2 = x2s; p.w = ws; p.bias = bias; p.y = y; p.ys = ys;
+  p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
+  p.Hout = pl.Hout; p.Wout = pl.Wout; p.Heff = pl.Heff; p.Weff = pl.Weff;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.subpix = d->upsample == 2 ? 1 : 0; p.hw_src = d->Hin * d->Win;
+  if (p.subpix) { p.KH = p.KW = 2; p.Heff = d->Hin; p.Weff = d->Win; }
+  p.M = pl.M; p.K = pl.K; p.HWout = pl.Hout * pl.Wout;
+  p.cgroups = pl.cgroups; p.cg_per_split = pl.cg_per_split; p.splitk = pl.splitk;
+  p.tiles_m = cdiv(pl.M, pl.t.BM); p.tiles_n = d->Cout / pl.t.BN;
+  p.slab = (long)pl.M * d->Cout;
+  p.bytes1 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C1);
+  p.bytes2 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C2);
+  p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1));
+  p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
+  if (pl.splitk == 1 && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout / pl.t.BM; }
+  if (pl.splitk > 1) {
+    const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
+    MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);
+    p.y = reinterpret_cast<float*>(workspace);
+    p.ys = nullptr;
+  }
+  const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
+  const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
+  {
+    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * 3.0);
+    switch (pl.t.id) {
+      case 31: rc = launch_f16x2<128, 256, 2, 4>(p, s); break;
+      case 32: rc = launch_f16x2<256, 128, 4, 2>(p, s); break;
+      case 33: rc = launch_f16x2<128, 128, 2, 4>(p, s); break;
+      case 34: rc = launch_f16x2<128, 128, 4, 2>(p, s); break;
+      case 35: rc = launch_f16x2<256, 64, 4, 2>(p, s); break;
+      case 36: rc = launch_f16x2<128, 64, 4, 2>(p, s); break;
+      case 37: rc = launch_f16x2<64, 256, 1, 8>(p, s); break;
+      default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
+    }
+  }
+  if (rc) return rc;
+  if (pl.splitk > 1) {
+    const int HW = p.HWout;
+    ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1 + (ys ? 1 : 0)));
+    if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ fp16-pair copy) in one streaming pass
+      const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
+      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, GnFinal{}, ys);
+      return check_launch("splitk_reduce_stats");
+    }
+    const long n4 = (long)pl.M * d->Cout / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4, d->Cout,
+                       pl.splitk, p.slab, ys);
+    return check_launch("splitk_reduce");
+  }
+  return MF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// conv_plan.h -- what the two convolution translation units (conv.hip: fp32 / bf16-triplet kernels; conv_f16x2.hip: fp16-pair kernel) share:
+// output geometry, the split-K reducer, and the cross-unit planner hooks.
+#pragma once
+#include "common.h"
+#include "split_f16.h"
+
+namespace mf {
+
+struct TileCfg { int id, BM, BN, WM, WN, BK; };
+
+struct Plan {
+  bool igemm;
+  TileCfg cfg;
+  int splitk, nk_per_split;
+  int Hout, Wout, Heff, Weff, M, K;
+};
+
+
+inline int fill_geometry(const MfConvDesc* d, Plan* pl) {
+  MF_REQUIRE(d != nullptr, MF_EINVAL, "conv: null desc");
+  MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
+  MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
+  MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
+  MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
+  MF_REQUIRE(d->precision >= 0 && d->precision <= 5, MF_EINVAL, "conv: precision flag %d", d->precision);
+  MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
+  MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
+  MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
+  const int up = d->upsample ? 1 : 0;
+  pl->Heff = d->Hin << up;
+  pl->Weff = d->Win << up;
+  pl->Hout = (pl->Heff + 2 * d->pad - d->KH) / d->stride + 1;
+  pl->Wout = (pl->Weff + 2 * d->pad - d->KW) / d->stride + 1;
+  MF_REQUIRE(pl->Hout > 0 && pl->Wout > 0, MF_EINVAL, "conv: empty output");
+  const long M = (long)d->N * pl->Hout * pl->Wout;
+  MF_REQUIRE(M < (1L << 31) && M * d->Cout < (1L << 40), MF_EUNSUPPORTED, "conv: problem too large");
+  pl->M = (int)M;
+  pl->K = (d->upsample == 2 ? 4 : d->KH * d->KW) * (d->C1 + d->C2);  // sub-pixel form: 2x2 taps per phase
+  return MF_OK;
+}
+
+
+// split-K reduction: y = sum_z slabs[z] + bias (+ the fp16-pair copy of y)
+template <int UNUSED = 0>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
+                                     long n4, int Cout, int splitk, long slab, void* __restrict__ ys) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const long e = i * 4;
+    float4 s = *reinterpret_cast<const float4*>(slabs + e);
+    for (int z = 1; z < splitk; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * slab + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + (e % Cout));
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    *reinterpret_cast<float4*>(y + e) = s;
+    if (ys) store_split4(ys, e, s.x, s.y, s.z, s.w);
+  }
+}
+
+
+// conv_f16x2.hip
+int f16x2_gn_parts(const MfConvDesc* d, int G);
+size_t f16x2_workspace_bytes(const MfConvDesc* d);
+// conv.hip
+int igemm_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
+
+}  // namespace mf

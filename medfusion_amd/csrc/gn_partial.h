@@ -2,6 +2,7 @@
 // pass) and conv.hip (fused into the split-K reduction: the reducer already streams every output element once).
 #pragma once
 #include "common.h"
+#include "split_f16.h"
 
 namespace mf {
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void gn_arrive_and_finalize(const GnFinal& f, const d
 template <bool REDUCE>
 __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int HW, int C, int G,
                                                                    int nslabs, long slab, const float* __restrict__ bias, float* __restrict__ y,
-                                                                   const GnFinal fin) {
+                                                                   const GnFinal fin, void* __restrict__ ys = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][Cs][2], then (fused finalize) 2*256 doubles + flag
   const int chunks = gridDim.x, chunk = blockIdx.x, n = blockIdx.y;
   const int Cs = C / gridDim.z, c_off = blockIdx.z * Cs;  // this workgroup's channel slice
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
           }
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           *reinterpret_cast<float4*>(y + e) = v;
+          if (ys) store_split4(ys, e, v.x, v.y, v.z, v.w);
         }
         s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
         q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);

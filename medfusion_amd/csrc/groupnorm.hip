@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const double* __res
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual,
                                                         const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
-                                                        int HW, int C, int G, int act) {
+                                                        int HW, int C, int G, int act, void* __restrict__ outs) {
   const int C4 = C >> 2;
   const int cpg = C / G;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    if (outs) store_split4(outs, i * 4, e[0], e[1], e[2], e[3]);
   }
 }
 
@@ -172,7 +173,13 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
 
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
                     int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream) {
+  return mf_gn_apply_split_f32(x, stats, gamma, beta, residual, emb, emb_stride, out, nullptr, N, HW, C, G, act, stream);
+}
+
+int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
+                          int64_t emb_stride, float* out, void* out_split, int N, int HW, int C, int G, int act, void* stream) {
   MF_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, MF_EINVAL, "gn_apply: bad args");
+  MF_REQUIRE(!out_split || C % 8 == 0, MF_EUNSUPPORTED, "gn_apply: the fp16-pair output needs C %% 8 == 0");
   MF_REQUIRE(C % 4 == 0, MF_EUNSUPPORTED, "gn_apply: C=%d must be a multiple of 4", C);
   MF_REQUIRE(!stats || (G > 0 && C % G == 0), MF_EINVAL, "gn_apply: C=%d G=%d", C, G);
   MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply: gamma/beta must both be given or both NULL");
@@ -180,11 +187,11 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
   hipStream_t s = (hipStream_t)stream;
   const long total4 = (long)N * HW * (C / 4);
   const double nelem = (double)N * HW * C;
-  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0)));
+  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
   long blocks = (total4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
-                     G > 0 ? G : 1, act);
+                     G > 0 ? G : 1, act, out_split);
   return check_launch("gn_apply");
 }
 

@@ -1,0 +1,48 @@
+// split_f16.h -- the fp16-pair form of an fp32 tensor (MF_CONV_FP32_F16X2 operands), shared by the kernels that produce it.
+//   x ~ hi + lo' / 2048,   hi = RN16(x),   lo' = RN16((x - hi) * 2048)      (the subtraction and the scaling are exact)
+// 23 of the 24 significand bits survive: |x - hi - lo'/2048| <= 2^-23 |x| (one ulp of the fp32 value at most; exact for 3 values of 4).
+// Storage: groups of 8 consecutive channels as 32 bytes [hi x 8][lo' x 8] -- 4 bytes per element, like fp32.
+// Range: |x| <= 65504 (clamped); below 2^-14 the absolute accuracy is 2^-36.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mf {
+
+typedef float sf_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sf_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 sf_f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f, kF16Max = 65504.f;
+
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  a = __builtin_fminf(__builtin_fmaxf(a, -kF16Max), kF16Max);
+  b = __builtin_fminf(__builtin_fmaxf(b, -kF16Max), kF16Max);
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;                             // round to nearest even
+  const float ra = (a - (float)ha) * kLoScale, rb = (b - (float)hb) * kLoScale;  // both operations exact
+  const sf_f16x2 h = {ha, hb}, l = {(_Float16)ra, (_Float16)rb};
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// 8 consecutive channels -> the 32-byte group [hi x 8][lo' x 8]
+__device__ __forceinline__ void split8_f16(const sf_f32x4 v0, const sf_f32x4 v1, sf_u32x4& hi, sf_u32x4& lo) {
+  const float a0 = v0[0], a1 = v0[1], a2 = v0[2], a3 = v0[3], b0 = v1[0], b1 = v1[1], b2 = v1[2], b3 = v1[3];
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2_f16(a0, a1, h0, l0);
+  split2_f16(a2, a3, h1, l1);
+  split2_f16(b0, b1, h2, l2);
+  split2_f16(b2, b3, h3, l3);
+  hi = sf_u32x4{h0, h1, h2, h3};
+  lo = sf_u32x4{l0, l1, l2, l3};
+}
+// 4 consecutive channels starting at element index e (a multiple of 4) of a tensor whose innermost extent is a multiple of 8
+__device__ __forceinline__ void store_split4(void* ys, long e, float a, float b, float c, float d) {
+  unsigned h0, h1, l0, l1;
+  split2_f16(a, b, h0, l0);
+  split2_f16(c, d, h1, l1);
+  sf_u32x2* o = reinterpret_cast<sf_u32x2*>(ys) + (e >> 3) * 4 + ((e >> 2) & 1);
+  o[0] = sf_u32x2{h0, h1};
+  o[2] = sf_u32x2{l0, l1};
+}
+
+}  // namespace mf

@@ -90,6 +90,70 @@ def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- fp16-pair operands (MF_CONV_FP32_F16X2)
+# The fp16-pair form of an activation travels as an attribute of the fp32 tensor it mirrors (`t._mf_split`, an int32 tensor of the
+# same shape).  Producers that can emit it for free set it (gn_apply(split=True), conv2d_f16x2(split_out=True)); a consumer that
+# does not find it runs the stand-alone split pass once and caches the result on the tensor.  Every wrapper that writes INTO an
+# existing tensor (`out=`) drops a stale mirror first.
+def drop_split(t: Optional[torch.Tensor]) -> None:
+    if t is not None and getattr(t, "_mf_split", None) is not None:
+        t._mf_split = None
+
+
+def split_f16x2(x: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor (innermost extent % 8 == 0) -> its fp16-pair form, an opaque int32 tensor of the same shape"""
+    _gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[-1] % 8:
+        raise RuntimeError("split_f16x2: contiguous fp32 with innermost extent % 8 == 0")
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    L.check(L.load().mf_split_f16x2(x.data_ptr(), out.data_ptr(), x.numel(), stream()), "mf_split_f16x2")
+    return out
+
+
+def split_of(x: torch.Tensor) -> torch.Tensor:
+    s = getattr(x, "_mf_split", None)
+    if s is None:
+        s = split_f16x2(x)
+        x._mf_split = s
+    return s
+
+
+def conv_f16x2_ok(d: L.MfConvDesc) -> bool:
+    return bool(L.load().mf_conv2d_f16x2_ok(C.byref(d)))
+
+
+def conv_plan(d: L.MfConvDesc):
+    """(tile id, split-K factor) the planner picks for `d`; (0, 0) if it is not on an implicit-GEMM kernel"""
+    t, k = C.c_int32(), C.c_int32()
+    L.check(L.load().mf_conv2d_plan_query(C.byref(d), C.byref(t), C.byref(k)), "mf_conv2d_plan_query")
+    return t.value, k.value
+
+
+def conv2d_f16x2(x1: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, split_out: bool = False, gn_groups: int = 0, gn_parts: int = 0):
+    """MF_CONV_FP32_F16X2 convolution of fp32 NHWC tensors whose fp16-pair mirrors are made on demand.
+    Returns y, or (y, partial [N, parts, G, 2]) when gn_groups > 0 (statistics of the GroupNorm that follows)."""
+    _gpu(x1, x2, w_split, bias)
+    lib = L.load()
+    x1s = split_of(x1)
+    x2s = split_of(x2) if x2 is not None else None
+    ho, wo = conv_out_hw(d)
+    if out is None:
+        out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
+    else:
+        drop_split(out)
+    ys = torch.empty(out.shape, dtype=torch.int32, device=x1.device) if split_out else None
+    partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=x1.device) if gn_groups else None
+    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
+    ws = Workspace.get(need, x1.device) if need else None
+    rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), w_split.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ys), _ptr(ws), need, _ptr(partial),
+                             gn_groups, C.byref(d), stream())
+    L.check(rc, "mf_conv2d_f16x2")
+    if split_out:
+        out._mf_split = ys
+    return (out, partial) if gn_groups else out
+
+
 def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,
                    tile_hint=0, splitk_hint=0, precision=0) -> L.MfConvDesc:
     return L.MfConvDesc(N, Hin, Win, C1, C2, Cout, k, k, stride, pad, upsample, in_layout, out_layout, tile_hint, splitk_hint, precision)
@@ -121,6 +185,8 @@ def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     if out is None:
         shape = (d.N, d.Cout, ho, wo) if d.out_layout == L.LAYOUT_NCHW else (d.N, ho, wo, d.Cout)
         out = torch.empty(shape, dtype=torch.float32, device=x1.device)
+    else:
+        drop_split(out)
     need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
     rc = lib.mf_conv2d_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, C.byref(d), stream())
@@ -233,6 +299,8 @@ def gn_apply_partial(x: torch.Tensor, partial: torch.Tensor, parts: int, gamma, 
     n, h, w, c = x.shape
     if out is None:
         out = torch.empty_like(x)
+    else:
+        drop_split(out)
     rc = L.load().mf_gn_apply_partial_f32(x.data_ptr(), partial.data_ptr(), parts, eps, _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride,
                                           out.data_ptr(), n, h * w, c, G, act, stream())
     L.check(rc, "mf_gn_apply_partial_f32")
@@ -252,14 +320,21 @@ def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
 
 
 def gn_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
-             emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None, split: bool = False) -> torch.Tensor:
+    """split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution)"""
     _gpu(x, stats, gamma, beta, residual, emb)
     n, h, w, c = x.shape
     if out is None:
         out = torch.empty_like(x)
-    rc = L.load().mf_gn_apply_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
-                                  n, h * w, c, G, act, stream())
-    L.check(rc, "mf_gn_apply_f32")
+    else:
+        drop_split(out)
+    split = split and c % 8 == 0
+    outs = torch.empty(out.shape, dtype=torch.int32, device=x.device) if split else None
+    rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
+                                        _ptr(outs), n, h * w, c, G, act, stream())
+    L.check(rc, "mf_gn_apply_split_f32")
+    if split:
+        out._mf_split = outs
     return out
 
 
@@ -381,6 +456,8 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     _gpu(a, b)
     if out is None:
         out = torch.empty_like(a)
+    else:
+        drop_split(out)
     L.check(L.load().mf_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), stream()), "mf_add_f32")
     return out
 
@@ -413,7 +490,7 @@ def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> tor
 
 # ----------------------------------------------------------------------------- launch timing
 class prof:
-    """with prof() as p: ...; p.table() -> {family: (ms, launches, flops, bytes)}"""
+    """with prof() as p: ...; p.table() -> {family: (ms, launches, algorithmic flops, bytes, executed flops)}"""
 
     def __enter__(self):
         lib = L.load()
@@ -431,8 +508,8 @@ class prof:
         lib = L.load()
         out = {}
         for i, name in enumerate(L.FAMILIES):
-            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-            L.check(lib.mf_prof_query(i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "mf_prof_query")
+            ms, n, fl, by, ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            L.check(lib.mf_prof_query2(i, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by), C.byref(ex)), "mf_prof_query2")
             if n.value:
-                out[name] = (ms.value, n.value, fl.value, by.value)
+                out[name] = (ms.value, n.value, fl.value, by.value, ex.value)
         return out

@@ -7,6 +7,11 @@ reproduces exactly that *sequence of draws* and is shard-invariant: rank r asks 
 [offset, offset+B) of the GLOBAL batch.
 
 * PhiloxDeviceNoise -- counter-based generator on the GPU (mf_philox_normal_f32); graph-capturable; default.
+                       Without an explicit seed every `begin()` takes a fresh 64-bit key from torch's default CPU generator
+                       (and so ADVANCES it, like the reference's randn_like advances its generator): successive `sample()` /
+                       `forward()` / `encode()` calls differ, `torch.manual_seed(s)` before a call reproduces it, and ranks that
+                       seed identically derive identical keys (shard invariance).  With `seed=` the key is fixed: the same
+                       call repeated gives the same draws (parity tests, bench steps use distinct seeds).
 * HostNoise         -- wraps any host callable `fn(shape) -> CPU tensor` producing the GLOBAL-batch draw
                        (e.g. torch's CPU generator, or the oracle's numpy Philox) and uploads the rank's rows:
                        used by parity tests to inject bit-identical noise into oracle and HIP path.
@@ -36,8 +41,11 @@ class PhiloxDeviceNoise(NoiseSource):
 
     def begin(self, local_batch, device, sample_offset=0, global_batch=None):
         super().begin(local_batch, device, sample_offset, global_batch)
-        # like the reference harness (`torch.manual_seed(0)` before each sample()), key on torch's seed
-        self._seed = int(torch.initial_seed()) if self.seed is None else int(self.seed)
+        if self.seed is None:
+            # stateful like the reference's default generator: the key comes out of torch's CPU generator, which moves on
+            self._seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        else:
+            self._seed = int(self.seed)
 
     def draw(self, shape, out=None):
         if out is None:

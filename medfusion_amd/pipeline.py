@@ -4,8 +4,8 @@ sample :312-317, interpolate :320-332.  Same signatures, keyword names, quirks (
 prefixes (`noise_estimator.`, `noise_scheduler.`, `latent_embedder.`, `ema_model.averaged_model.`).
 
 Differences, all outside the arithmetic: no streamlit/tqdm (Q16); noise comes from a NoiseSource
-(`noise=` keyword; default = device Philox keyed by torch.initial_seed(), so `torch.manual_seed(0)` before
-`sample()` is reproducible like the reference harness); `shard=(rank, world)` keyword partitions the batch
+(`noise=` keyword; default = device Philox keyed from torch's default CPU generator, which it advances: consecutive
+`sample()` calls differ and `torch.manual_seed(0)` before `sample()` is reproducible, like the reference harness); `shard=(rank, world)` keyword partitions the batch
 rows across GPUs with shard-invariant noise.  Training (`_step`) is out of scope.
 """
 from __future__ import annotations

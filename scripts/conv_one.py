@@ -25,19 +25,24 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x1 = torch.randn((n, h, w, c1), generator=g).to(dev)
 x2 = torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None
-wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
+wt = (torch.randn((4, co, 2, 2, c1 + c2) if ups == 2 else (co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
 b = torch.randn((co,), generator=g).to(dev)
 d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_hint=a.tile, splitk_hint=a.splitk, precision=a.precision)
 if a.precision == 3:
     wt = K.split_conv_weight(wt)
-y = K.conv2d(x1, wt, b, d, x2=x2)
+if a.precision == 5:
+    wt = K.split_f16x2(wt)
+    conv = K.conv2d_f16x2
+else:
+    conv = K.conv2d
+y = conv(x1, wt, b, d, x2=x2)
 for _ in range(5):
-    K.conv2d(x1, wt, b, d, x2=x2, out=y)
+    conv(x1, wt, b, d, x2=x2, out=y)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.reps):
-    K.conv2d(x1, wt, b, d, x2=x2, out=y)
+    conv(x1, wt, b, d, x2=x2, out=y)
 e1.record()
 torch.cuda.synchronize()
 ho, wo = K.conv_out_hw(d)

@@ -60,7 +60,25 @@ def _split_cache(w):
     return _W3[k]
 
 
+_WH = {}
+
+
 def time_conv(x1, x2, w, b, d, reps):
+    if d.precision == 5:
+        k = w.data_ptr()
+        if k not in _WH:
+            _WH.clear()
+            _WH[k] = K.split_f16x2(w)
+        wh = _WH[k]
+        y = K.conv2d_f16x2(x1, wh, b, d, x2=x2)   # (the activations' fp16-pair mirrors are cached on the tensors by this first call)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            K.conv2d_f16x2(x1, wh, b, d, x2=x2, out=y)
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps
     if d.precision == 3:
         w = _split_cache(w)
     y = K.conv2d(x1, w, b, d, x2=x2)
@@ -81,7 +99,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
-    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms, 2: + chunk sums, 3: 1 with pre-split weights")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms, 2: + chunk sums, 3: 1 with pre-split weights, 5: fp16 pairs (LDS-DMA kernel)")
     ap.add_argument("--tiles", default="", help="comma list of tile ids to sweep (default: all built for the precision)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -92,22 +110,27 @@ def main():
         if args.only and args.only not in name:
             continue
         pad = 1 if k == 3 else 0
+        if args.precision == 5 and ups:
+            ups = 2
         x1 = torch.randn((n, h, w_, c1), generator=g).to(dev)
         x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
-        wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
+        wt = (torch.randn((4, co, 2, 2, c1 + c2) if ups == 2 else (co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
         b = torch.randn((co,), generator=g).to(dev)
         d0 = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, precision=args.precision)
         ho, wo = K.conv_out_hw(d0)
         M, Kk = n * ho * wo, k * k * (c1 + c2)
         gf = 2.0 * M * co * Kk / 1e9
+        if args.precision == 5 and not K.conv_f16x2_ok(d0):
+            print(f"{name:24s} not on the fp16-pair kernel")
+            continue
         time_conv(x1, x2, wt, b, d0, args.reps)  # clock/cache warm-up
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
+            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37) if args.precision == 5 else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
-                bn = {1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
-                bm = {1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
+                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
+                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
                 if ups == 2 and (h * w_) % bm:
                     continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
@@ -116,6 +139,8 @@ def main():
                     continue
                 for sk in (1, 2, 4, 8, 16):
                     if sk > 1 and Kk // 32 // sk < 8:
+                        continue
+                    if args.precision == 5 and sk > (c1 + c2) // 32:
                         continue
                     d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))

@@ -15,4 +15,5 @@ for set in "${SETS[@]}"; do
   i=$((i+1))
   timeout 120 rocprofv3 --pmc $set --kernel-trace -d $R/$OUT -o pmc$i --output-format csv -- python $R/scripts/conv_one.py --shape $SHAPE --tile $TILE --splitk $SK --precision $PREC --reps 10 > $R/$OUT/run$i.log 2>&1
 done
-python $R/scripts/pmc_summary.py $R/$OUT
+KN=conv_igemm; [ "$PREC" = "5" ] && KN=conv_f16x2
+python $R/scripts/pmc_summary.py $R/$OUT $KN

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
-    assert lib.mf_version() == 101
+    assert lib.mf_version() == 200
     assert lib.mf_prof_family_name(0) == b"conv_igemm"
 
 
@@ -60,7 +60,7 @@ def test_product_never_imports_the_oracle():
             for n in names:
                 assert not n.split(".")[0] in ("oracle", "tests"), f"{py} imports {n}"
         assert "/root/reference" not in py.read_text()
-    for src in (ROOT / "medfusion_amd" / "csrc").iterdir():
+    for src in (p for p in (ROOT / "medfusion_amd" / "csrc").iterdir() if p.is_file()):
         assert "oracle" not in src.read_text().lower().replace("oracle/synth.py: philox_normal is the spec", "")
 
 

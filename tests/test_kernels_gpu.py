@@ -574,3 +574,99 @@ def test_conv_gn_apply_fused_epilogue(dev, shape, prec):
     got2 = K.conv2d_gn_apply(x, wk, b, d, G, parts, None, None, eps=1e-5, act=0)   # no affine, no act, no residual, no emb
     want2 = K.gn_apply(y, stats, None, None, G, 0)
     assert relerr(got2, want2) < 2e-6
+
+
+# ----------------------------------------------------------------------------- MF_CONV_FP32_F16X2 (fp16 pairs, LDS-DMA kernel)
+def test_split_f16x2_format(dev):
+    """The fp16-pair form: groups of 8 channels [hi x 8][lo x 8]; hi + lo / 2048 reproduces x to one ulp of its fp32 value
+    (2^-23 |x|: 23 of the 24 significand bits; exact for most values), values past the fp16 range clamp to +-65504, tiny values keep
+    an absolute accuracy of 2^-36."""
+    from medfusion_amd import kernels as K
+    x = _rand("splitx", (3, 5, 7, 64), 3.0)
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-7, -3e-9, 70000.0, -1e9, 65504.0, 2.0 ** -14])
+    xs = K.split_f16x2(x.to(dev)).cpu()
+    raw = xs.view(torch.int16).view(3, 5, 7, 8, 2, 8)            # [.., group, piece, 8] fp16 bit patterns
+    hi = raw[..., 0, :].contiguous().view(torch.float16).double().reshape(3, 5, 7, 64)
+    lo = raw[..., 1, :].contiguous().view(torch.float16).double().reshape(3, 5, 7, 64)
+    back = hi + lo / 2048.0
+    ref = x.double().clamp(-65504.0, 65504.0)
+    err = (back - ref).abs()
+    assert bool((err <= ref.abs() * 2.0 ** -23 + 2.0 ** -36).all()), float((err / (ref.abs() + 1e-30)).max())
+    assert float((err == 0).double().mean()) > 0.6                                 # three values out of four are exact
+    rms = float(((err[ref.abs() > 1e-3] / ref.abs()[ref.abs() > 1e-3]) ** 2).mean().sqrt())
+    assert rms < 2.0 ** -24, rms                                                   # on average well below one fp32 rounding error
+
+
+F16X2_CASES = [
+    # (N, H, W, C1, C2, Cout, k, stride, ups)
+    (2, 8, 8, 32, 0, 64, 3, 1, 0),
+    (2, 8, 8, 64, 32, 128, 3, 1, 0),     # two-source (skip concat)
+    (3, 10, 12, 32, 0, 64, 3, 2, 0),     # BasicDown stride 2, ragged M
+    (2, 8, 8, 32, 0, 256, 3, 1, 2),      # BasicUp, sub-pixel form (hw_src = 64: only the 64-row tile fits a phase)
+    (2, 16, 16, 64, 0, 128, 3, 1, 2),    # BasicUp, sub-pixel form (hw_src = 256)
+    (2, 8, 8, 64, 0, 128, 1, 1, 0),      # 1x1 conv_res
+    (1, 16, 16, 256, 0, 256, 3, 1, 0),   # published 32^2-level shape (smaller HW)
+    (2, 8, 8, 512, 512, 512, 3, 1, 0),   # out-block two-source, long K -> split-K
+    (1, 7, 9, 96, 0, 192, 3, 1, 0),      # ragged M, Cout = 192
+]
+F16X2_TILES = {31: (128, 256), 32: (256, 128), 33: (128, 128), 34: (128, 128), 35: (256, 64), 36: (128, 64), 37: (64, 256)}
+
+
+def _f16x2_tiles(case):
+    n, h, w, c1, c2, co, k, stride, ups = case
+    return [0] + [t for t, (bm, bn) in F16X2_TILES.items() if co % bn == 0 and (ups != 2 or (h * w) % bm == 0)]
+
+
+@pytest.mark.parametrize("case,tile", [(c, t) for c in F16X2_CASES for t in _f16x2_tiles(c)])
+def test_conv_f16x2(dev, case, tile):
+    """fp32 through pairs of fp16 (23-bit operands, 3 product terms, fp32 accumulate): error against an fp64 convolution within the
+    fp32 tolerance AND of the same class as the fp32-MFMA kernel's own error; the fp16-pair mirror of the output equals the split of
+    the output; the fused GroupNorm partial statistics equal the stand-alone pass."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    x = _rand(f"cx{case}", (n, c1, h, w))
+    x2 = _rand(f"cy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"cw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"cb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want = _conv_ref(x, x2, wt, b, stride, pad, 1 if ups else 0)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wp = K.pack_upconv_weight(wt.to(dev)) if ups == 2 else K.pack_conv_weight(wt.to(dev))
+    wh = K.split_f16x2(wp)
+    d0 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups)
+    e0 = relerr(K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d0, x2=x2d)), want)   # the fp32-MFMA kernel
+    cgroups = (c1 + c2) // 32
+    for sk in ([0] if tile == 0 else [0, 1, 2, 3]):
+        if sk > cgroups:
+            continue
+        d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=5)
+        assert K.conv_f16x2_ok(d), (case, tile, sk)
+        y = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, split_out=True)
+        e = relerr(K.nhwc_to_nchw(y), want)
+        assert e < 1e-5, (case, tile, sk, e, e0)
+        assert e < 3 * e0 + 1e-6, (case, tile, sk, e, e0)
+        assert torch.equal(y._mf_split, K.split_f16x2(y)), (case, tile, sk)
+        G = 8
+        parts = K.conv_gn_parts(d, G)
+        if parts:
+            y2, partial = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, gn_groups=G, gn_parts=parts)
+            assert torch.equal(y2, y)
+            ref_p, ref_parts = K.gn_stats_partial(y, G)
+            got = partial.sum(1).cpu()
+            ref = ref_p.sum(1).cpu()
+            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6), (case, tile, sk)
+
+
+def test_gn_apply_split_mirror(dev):
+    """gn_apply(split=True) writes the fp16-pair mirror of exactly what it writes in fp32"""
+    from medfusion_amd import kernels as K
+    x = _rand("gas_x", (2, 6, 6, 64)).to(dev)
+    res = _rand("gas_r", (2, 6, 6, 64)).to(dev)
+    gamma, beta = _rand("gas_g", (64,)).to(dev), _rand("gas_b", (64,)).to(dev)
+    stats = K.gn_stats(x, 8)
+    y = K.gn_apply(x, stats, gamma, beta, 8, 1, res, split=True)
+    assert torch.equal(y, K.gn_apply(x, stats, gamma, beta, 8, 1, res))
+    assert torch.equal(y._mf_split, K.split_f16x2(y))
+    K.add(y, res, out=y)                      # writing into a tensor drops its (now stale) mirror
+    assert getattr(y, "_mf_split", None) is None

@@ -35,9 +35,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 0], ids=["split3", "fp32mfma"], autouse=True)
+@pytest.fixture(params=[5, 1, 0], ids=["f16x2", "split3", "fp32mfma"], autouse=True)
 def conv_precision(request):
-    """every parity test runs on both conv arithmetics (MF_CONV_FP32_SPLIT3 = the default, MF_CONV_FP32), same tolerances"""
+    """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3, MF_CONV_FP32), same tolerances"""
     from medfusion_amd import blocks as BLK
     old = BLK.CONV_PRECISION
     BLK.CONV_PRECISION = request.param

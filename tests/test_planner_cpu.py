@@ -20,7 +20,7 @@ def test_which_convs_run_on_the_implicit_gemm_kernel():
     assert lib.mf_conv2d_is_igemm(C.byref(_d(2, 8, 8, 48, 0, 64))) == 0                # Cin % 32 != 0
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("prec", [0, 1, 2, 3, 4, 5])
 def test_split_k_workspace_and_gn_parts_are_consistent(prec):
     lib = L.load()
     for shape in [(16, 32, 32, 256, 0, 256), (16, 16, 16, 512, 0, 512), (16, 8, 8, 1024, 1024, 1024), (4, 64, 64, 256, 0, 256), (1, 256, 256, 64, 0, 64)]:
@@ -31,9 +31,12 @@ def test_split_k_workspace_and_gn_parts_are_consistent(prec):
         assert ws % out_bytes == 0                      # 0 (no split-K) or splitk slabs of the output size
         sk = ws // out_bytes
         assert sk == 0 or 2 <= sk <= 16
-        parts = lib.mf_conv2d_gn_parts(C.byref(d), 32)
+        G = 32 if co >= 256 else 8                      # UNet levels: 32 groups; VAE levels: 8 (the fp16-pair epilogue needs >= 8 channels per group)
+        parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
         assert 0 < parts <= max(16, h * w // 64)       # every large conv of the path can emit GroupNorm partials
-        if prec in (1, 2, 3):                            # split modes: one accumulation chain <= 96 chunks of 32
+        if prec == 5:
+            assert lib.mf_conv2d_f16x2_ok(C.byref(d)) == 1
+        if prec in (1, 2, 3, 5):                         # split modes: one accumulation chain <= 96 chunks of 32
             chunks = 9 * (shape[3] + shape[4]) // 32
             assert chunks / max(sk, 1) <= 96
 
@@ -57,10 +60,10 @@ def test_precision_enum_matches_header():
     import re
     from pathlib import Path
     txt = (Path(__file__).resolve().parents[1] / "include" / "medfusion_hip.h").read_text()
-    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3 = (\d), MF_CONV_FP32_SPLIT3_CHUNKSUM = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d) \}", txt)
-    assert m and [int(v) for v in m.groups()] == [0, 1, 2, 3, 4]
+    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3 = (\d), MF_CONV_FP32_SPLIT3_CHUNKSUM = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d),\s+MF_CONV_FP32_F16X2 = (\d) \}", txt)
+    assert m and [int(v) for v in m.groups()] == [0, 1, 2, 3, 4, 5]
     from medfusion_amd import blocks as BLK
-    assert BLK.CONV_PRECISION in (0, 1, 2)  # the reduced-precision mode (4) is never a default
+    assert BLK.CONV_PRECISION in (0, 1, 2, 5)  # the reduced-precision mode (4) is never a default
 
 
 def test_planner_properties_over_many_descriptors():
