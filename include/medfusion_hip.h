@@ -98,16 +98,20 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
                   void* workspace, size_t workspace_bytes, const MfConvDesc* d, void* stream);
 
 /* --- MF_CONV_FP32_F16X2 (same reference call sites as mf_conv2d_f32: conv_blocks.py:185,238,66,123-125, unet2.py:259)
- * mf_split_f16x2: fp32 [.., C] (n elements, n % 8 == 0, innermost extent a multiple of 8) -> the fp16-pair form (n * 4 bytes); used for
- *   packed weights ([rows][K], either packing) once at load time and for activations no producer kernel has split.
- * mf_conv2d_f16x2: x1s / x2s / ws in fp16-pair form; y fp32 NHWC; ys optional fp16-pair copy of y (for the next convolution);
- *   gn_partial optional: statistics of the following GroupNorm(G), [N][parts][G][2] doubles, parts = mf_conv2d_gn_parts(d, G) > 0.
- *   Split-K plans reduce through `workspace` (mf_conv2d_workspace_bytes) with the reducer emitting y, ys and the statistics.
+ * mf_split_f16x2: fp32 [rows][per_row] (per_row % 8 == 0) -> the fp16-pair form (4 bytes per element), row r scaled by
+ *   2^-(floor(log2 bound[r]) - 14) (bound NULL: no scaling).  Used for packed weights (rows = 1, bound = max|w|) once at load time and for
+ *   activations no producer kernel has split (rows = N samples).
+ * mf_conv2d_f16x2: x1s / x2s / ws in fp16-pair form with their bounds (x*_bound: [N] floats or NULL = unscaled; w_bound: the scalar the
+ *   weights were split with, 0 = unscaled); y fp32 NHWC.  gn_partial optional: statistics of the following GroupNorm(G), [N][parts][G][2]
+ *   doubles, parts = mf_conv2d_gn_parts(d, G) > 0.  y_bound optional ([N], ZERO on entry): measured max |y| per sample (atomic max), the
+ *   operand bound of y for convolutions that consume it un-normalised.  Split-K plans reduce through `workspace`
+ *   (mf_conv2d_workspace_bytes), the reducer emitting y, the statistics and y_bound.
  * mf_conv2d_plan_query: the tile id and split-K factor the planner picks for `d` (any precision; 0, 0 = not on the implicit-GEMM path). */
 int mf_conv2d_f16x2_ok(const MfConvDesc* d);
-int mf_split_f16x2(const float* x, void* xs, int64_t n, void* stream);
-int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* ys, void* workspace,
-                    size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream);
+int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64_t per_row, void* stream);
+int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound,
+                    const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, double* gn_partial, int G,
+                    const MfConvDesc* d, void* stream);
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
 
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
@@ -156,10 +160,17 @@ int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, fl
  * out may alias x. */
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                     const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream);
-/* the same pass, also writing the fp16-pair form of `out` (operand of a following MF_CONV_FP32_F16X2 convolution; C % 8 == 0) */
+/* The same pass, also writing the fp16-pair form of `out` (operand of a following MF_CONV_FP32_F16X2 convolution; C % 8 == 0).
+ * A fp16-pair tensor carries a per-sample power-of-two scale derived from an UPPER BOUND of |value| over the sample (fp16 stops at
+ * 65504, an un-normalised residual stream does not): the pass derives the bound of its output from its inputs --
+ *   bound[n] = (stats ? bconst : x_bound[n]) + res_bound[n] + emb_bound[n],  bconst >= max|act(gn(x) gamma + beta)| =
+ *   max|gamma| sqrt(group size) + max|beta| -- scales sample n by 2^-(floor(log2 bound[n]) - 14) and publishes bound[n] in out_bound. */
 int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
-                          const float* emb, int64_t emb_stride, float* out, void* out_split, int N, int HW, int C, int G, int act,
-                          void* stream);
+                          const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound,
+                          const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
+/* bound[n] = max |x[n][:]| over per_row elements (atomic max: `bound` must be ZERO on entry).  The measured operand bound of tensors no
+ * producer bounded analytically (network input convolutions, outputs of convolutions without a GroupNorm, embedding rows). */
+int mf_maxabs_rows_f32(const float* x, float* bound, int N, int64_t per_row, void* stream);
 
 /* ------------------------------------------------------------------ small dense ops
  * mf_linear_f32: y[b*y_stride + o] = sum_i f(x[b*x_stride + i]) * w[o*In + i] + bias[o] (+ y if accumulate);

@@ -69,7 +69,7 @@ class _Packed:
         """the same weights as fp16 pairs (MF_CONV_FP32_F16X2), derived once from the fp32 packing"""
         wp = self.get(weight)
         if self._wh is None:
-            self._wh = K.split_f16x2(wp)
+            self._wh = K.split_weight_f16x2(wp)   # (pairs scaled by max |w|, that max)
         return self._wh
 
     def get_bf16(self, weight: torch.Tensor) -> torch.Tensor:
@@ -121,7 +121,7 @@ class Conv(nn.Module):
         self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
 
-    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, split_out):
+    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out):
         """MF_CONV_FP32_F16X2, or None when this convolution is not on that kernel"""
         key = ("f16x2", n, h, w, c1, c2, gn_groups)
         ent = self._descs.get(key)
@@ -136,7 +136,7 @@ class Conv(nn.Module):
         pk = self._packed_sub if d.upsample == 2 else self._packed
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
-            return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, split_out=split_out)
+            return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, measure_out=measure_out)
         ho, wo = K.conv_out_hw(d)
         if parts > 0:
             y, partial = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, gn_groups=gn_groups, gn_parts=parts)
@@ -146,9 +146,9 @@ class Conv(nn.Module):
         return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)
 
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
-                gn_eps: float = 1e-5, split_out: bool = False):
+                gn_eps: float = 1e-5, measure_out: bool = False):
         """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2]).
-        split_out: in the fp16-pair mode, also emit the fp16-pair mirror of y (the output feeds another convolution directly)."""
+        measure_out: in the fp16-pair mode, also measure the per-sample max |y| (y feeds a convolution or a residual add un-normalised)."""
         x1, x2 = _split(x)
         if in_layout == L.LAYOUT_NCHW:
             n, c1, h, w = x1.shape
@@ -160,7 +160,7 @@ class Conv(nn.Module):
         prec = CONV_PRECISION
         if prec == 5:
             if rows is None and in_layout == L.LAYOUT_NHWC and out_layout == L.LAYOUT_NHWC:
-                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, split_out)
+                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out)
                 if r is not None:
                     return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
@@ -252,6 +252,16 @@ class GroupNorm(nn.Module):
             self.bias = nn.Parameter(torch.zeros(num_channels))
         else:
             self.weight = self.bias = None
+        self._bkey, self._bmax = None, (1.0, 0.0)
+
+    def bound_const(self, group_size: int) -> float:
+        """upper bound of |gn(x) * gamma + beta| (and of its Swish): a normalised group of n values has |value| <= sqrt(n - 1)"""
+        if self.weight is not None:
+            key = (self.weight._version, self.bias._version, self.weight.data_ptr())
+            if key != self._bkey:  # load-time host sync, cached
+                self._bmax = (float(self.weight.detach().abs().max().item()), float(self.bias.detach().abs().max().item()))
+                self._bkey = key
+        return self._bmax[0] * float(group_size) ** 0.5 + self._bmax[1]
 
 
 def _norm(norm_name, channels) -> GroupNorm:
@@ -301,7 +311,9 @@ def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
     nm = self.norm
     if isinstance(stats, tuple):  # ("partial", records, parts, eps): finalize inside the apply pass
         return K.gn_apply_partial(y, stats[1], stats[2], nm.weight, nm.bias, nm.num_groups, stats[3], int(self.has_act), residual, emb, emb_stride, out=y)
-    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=f16x2_mode())
+    split = f16x2_mode()
+    bc = nm.bound_const(y.shape[1] * y.shape[2] * (y.shape[3] // nm.num_groups)) if split else 0.0
+    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=split, bconst=bc)
 
 
 BasicBlock.conv_and_stats = _basicblock_conv_and_stats
@@ -324,7 +336,7 @@ class BasicResBlock(nn.Module):
                 raise RuntimeError("identity residual needs a single NHWC input")
             return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
         if not SIDE_STREAM_RESIDUAL:
-            res = self.conv_res(x, in_layout=in_layout)
+            res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
             return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
         # The 1x1 residual conv and the 3x3 conv read the same input and are independent: run the small one on a side
         # stream so its ramp-up/drain overlaps the big one (fork/join; works under graph capture too).
@@ -413,7 +425,7 @@ class BasicDown(nn.Module):
         self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
 
     def forward(self, x, emb=None):
-        return self.down_op(x, split_out=f16x2_mode())
+        return self.down_op(x, measure_out=f16x2_mode())
 
 
 class BasicUp(nn.Module):
@@ -428,7 +440,7 @@ class BasicUp(nn.Module):
         self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
 
     def forward(self, x, emb=None):
-        return self.up_op(x, split_out=f16x2_mode())
+        return self.up_op(x, measure_out=f16x2_mode())
 
 
 class SequentialEmb(nn.Sequential):

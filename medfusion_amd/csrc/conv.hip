@@ -635,11 +635,13 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
                          reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, fin);
       return check_launch("splitk_reduce_stats");
     }
-    const long n4 = (long)pl.M * d->Cout / 4;
+    const long p4 = (long)pl.Hout * pl.Wout * d->Cout / 4;   // float4s per sample
     ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
-    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4,
-                       d->Cout, pl.splitk, p.slab, (void*)nullptr);
+    int bx = (int)((p4 + 255) / 256);
+    const int cap = cdiv(2048, d->N);
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
+                       pl.splitk, p.slab, (unsigned*)nullptr);
     return check_launch("splitk_reduce");
   }
   return MF_OK;

@@ -7,7 +7,9 @@
 // out of 4).  A product is accumulated in fp32 on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32-MFMA rate) as three terms
 //   main  += wh * xh            cross += wh * xl' + wl' * xh            result = main + cross / 2048
 // the dropped term wl*xl is < 2^-22 |w x|.  Three matrix instructions per product instead of the six of the exact 3 x bf16 split
-// (MF_CONV_FP32_SPLIT3).  Range: |x| <= 65504 (the split clamps), values below 2^-14 keep an absolute accuracy of 2^-36.
+// (MF_CONV_FP32_SPLIT3).  Range: every operand tensor carries a per-sample power-of-two scale (split_f16.h) -- the kernel multiplies
+// its accumulators by the scales of the sample a pixel belongs to, and re-scales them once when the K loop moves from the first source
+// of a fused concat to the second (the two tensors have their own scales).
 //
 // Data movement.  Both operands go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA: no VGPR staging, no ds_write, no VALU on
 // the data), three LDS stages, one raw s_barrier per 32-channel chunk in the MIDDLE of the chunk's MFMA stream, counted vmcnt so that
@@ -38,7 +40,10 @@ struct ConvP2 {
   const void* w;    // [phases][Cout][taps][Cin/8][2][8] fp16 pairs
   const float* bias;
   float* y;         // fp32 NHWC output, or the split-K slabs
-  void* ys;         // optional fp16-pair copy of the output (splitk == 1)
+  const float* bound1;   // [N] per-sample bounds the sources were scaled with (split_f16.h), or null = unscaled
+  const float* bound2;
+  int wexp;              // the weights were split as w * 2^-wexp
+  unsigned* out_bound;   // optional [N]: measured max |y| per sample (atomic max, zero on entry; splitk == 1)
   int N, Hin, Win, C1, C2, Cin, Cout;
   int Hout, Wout, Heff, Weff, KH, KW, stride, pad;
   int M, K, HWout;
@@ -61,7 +66,7 @@ __device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; b
 #define MFC2_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST>
 __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   static_assert(WM * WN == 8, "8 waves");
   constexpr int FM = BM / WM, FN = BN / WN, TM = FM / 32, TN = FN / 32;
@@ -71,6 +76,9 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
   constexpr int NM = 3 * TM * TN;                           // MFMAs per 16-deep step
   constexpr int NR = 2 * (TM + TN);                         // fragment reads per step
+  constexpr int NF = (2 * NM + 2) / 3;                      // the reads of a step are issued behind its first NF MFMAs (the rest cover their latency)
+  static_assert(NST >= 3 && NST <= 6 && NST * STAGE <= 160 * 1024 && (NST - 1) * NL <= 63, "LDS stages");
+  static_assert((NR + NF - 1) / NF <= 2, "at most two reads per slot");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   const unsigned kbytes = (unsigned)p.K * 4u;                       // one weight row: K elements x 2 pieces x 2 bytes
   const unsigned qv = (unsigned)(phase_t * p.Cout + n0 + 8 * wave + lrow) * kbytes + slot16;
 
-  // load iterator (runs three chunks ahead of the compute)
+  // load iterator (runs NST chunks ahead of the compute)
   int l_cc = cg_beg, l_ky = 0, l_kx = 0, l_it = 0, l_st = 0;
   unsigned pbase[GP];
   unsigned l_cs4 = 0;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
 #define MFC2_LOAD_ADVANCE()                  \
   {                                          \
     ++l_it;                                  \
-    l_st = l_st == 2 ? 0 : l_st + 1;         \
+    l_st = l_st == NST - 1 ? 0 : l_st + 1;   \
     ++l_kx;                                  \
     if (l_kx == p.KW) { l_kx = 0; ++l_ky; }  \
     if (l_ky == p.KH) {                      \
@@ -204,6 +212,26 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
 
   f16x8 fx[2][TM][2], fw[2][TN][2];   // [step][sub-tile][piece]
 
+  // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source
+  const bool first_src1 = cg_beg * 32 < p.C1, last_src2 = (cg_end - 1) * 32 >= p.C1;
+  const int it_sw = (first_src1 && last_src2) ? (p.C1 / 32 - cg_beg) * taps : -1;   // first iteration that reads the second source
+  float f_sw[TM], f_out[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pm = min(m0 + wm * FM + i * 32 + (lane & 31), p.M - 1);
+    const int n = pm / p.HWout;
+    const int e1 = p.bound1 ? scale_exp_of(p.bound1[n]) : 0;
+    const int e2 = (p.bound2 && p.C2 > 0) ? scale_exp_of(p.bound2[n]) : 0;
+    f_sw[i] = exp2i(e1) * exp2i(-e2);
+    f_out[i] = exp2i(last_src2 ? e2 : e1) * exp2i(p.wexp);
+  }
+#define MFC2_SOURCE_SWITCH()                                                                                            \
+  if (__builtin_expect(it == it_sw, 0)) {                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { accm[i][j][r] *= f_sw[i]; accx[i][j][r] *= f_sw[i]; }          \
+  }
+
 // fragment read U (0 .. NR-1) of step S from the stage at byte offset SB
 #define MFC2_READ_UNIT(S, SB, U)                                                                                        \
   {                                                                                                                     \
@@ -226,13 +254,18 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   }
 
   if (nit > 0) {
-    // ---- prologue: up to three chunks in flight, wait for the first
+    // ---- prologue: up to NST chunks in flight, wait for the first
     MFC2_CHUNK_SETUP()
     MFC2_LOAD_ALL()
     MFC2_LOAD_ADVANCE()
-    if (nit > 1) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
-    if (nit > 2) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
-    if (nit > 2) { MFC2_WAIT_VM(2 * NL); } else if (nit > 1) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+#pragma unroll
+    for (int k = 1; k < NST; ++k)
+      if (nit > k) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
+    {
+      const int g = min(nit, NST) - 1;   // chunk groups that may stay in flight
+      if (g >= 5) { MFC2_WAIT_VM(5 * NL <= 63 ? 5 * NL : 0); } else if (g == 4) { MFC2_WAIT_VM(4 * NL <= 63 ? 4 * NL : 0); }
+      else if (g == 3) { MFC2_WAIT_VM(3 * NL); } else if (g == 2) { MFC2_WAIT_VM(2 * NL); } else if (g == 1) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+    }
     __builtin_amdgcn_s_barrier();
     MFC2_READ_UNIT(0, 0, 0) MFC2_READ_UNIT(0, 0, 1) MFC2_READ_UNIT(0, 0, 2) MFC2_READ_UNIT(0, 0, 3)
     if constexpr (NR > 4) { MFC2_READ_UNIT(0, 0, NR > 4 ? 4 : 0) MFC2_READ_UNIT(0, 0, NR > 4 ? 5 : 0) }
@@ -244,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
 #define MFC2_SLOT_A(N_, SB)                                                                                             \
   {                                                                                                                     \
     MFC2_MFMA(0, N_)                                                                                                    \
-    constexpr int lo_ = ((N_) * NR + NM - 1) / NM, hi_ = (((N_) + 1) * NR + NM - 1) / NM;                               \
+    constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(1, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(1, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
@@ -252,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
 #define MFC2_SLOT_B(N_, SB, DO_LOAD)                                                                                    \
   {                                                                                                                     \
     MFC2_MFMA(1, N_)                                                                                                    \
-    constexpr int lo_ = ((N_) * NR + NM - 1) / NM, hi_ = (((N_) + 1) * NR + NM - 1) / NM;                               \
+    constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(0, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(0, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
     constexpr int ll_ = ((N_) * NL + NM - 1) / NM, lh_ = (((N_) + 1) * NL + NM - 1) / NM;                               \
@@ -268,33 +301,39 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   if constexpr (NM > 6) { M_(NM > 6 ? 6 : 0, __VA_ARGS__) M_(NM > 6 ? 7 : 0, __VA_ARGS__) M_(NM > 6 ? 8 : 0, __VA_ARGS__)   \
                           M_(NM > 6 ? 9 : 0, __VA_ARGS__) M_(NM > 6 ? 10 : 0, __VA_ARGS__) M_(NM > 6 ? 11 : 0, __VA_ARGS__) }
 
-  // ---- main loop.  Iteration `it` (LDS stage st):
+  // ---- main loop.  Iteration `it` (LDS stage st = it % NST):
   //   first half : MFMAs of k-step 0 (fragments already in registers) | fragment reads of k-step 1 from stage st
   //   middle     : lgkmcnt(0) (stage st is fully read by this wave), vmcnt (chunk it+1 of this wave has landed), s_barrier
-  //   second half: MFMAs of k-step 1 | fragment reads of k-step 0 of chunk it+1 | DMA of chunk it+3 into stage st
+  //   second half: MFMAs of k-step 1 | fragment reads of k-step 0 of chunk it+1 | DMA of chunk it+NST into stage st
   int st = 0, it = 0;
-  for (; it + 3 < nit; ++it) {   // steady state: no branches
+  for (; it + NST < nit; ++it) {   // steady state
+    MFC2_SOURCE_SWITCH()
     const int sb = st * STAGE;
-    const int sn = (st == 2 ? 0 : st + 1) * STAGE;
+    const int sn = (st == NST - 1 ? 0 : st + 1) * STAGE;
     MFC2_REP12(MFC2_SLOT_A, sb)
     MFC2_WAIT_LGKM0();
-    MFC2_WAIT_VM(NL);
+    MFC2_WAIT_VM((NST - 2) * NL);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     MFC2_REP12(MFC2_SLOT_B, sn, true)
     MFC2_LOAD_ADVANCE()
-    st = st == 2 ? 0 : st + 1;
+    st = st == NST - 1 ? 0 : st + 1;
   }
-  for (; it < nit; ++it) {       // last three chunks: nothing left to load
+  for (; it < nit; ++it) {         // last NST chunks: nothing left to load; chunks it+1 .. nit-1 are still in flight
+    MFC2_SOURCE_SWITCH()
     const int sb = st * STAGE;
-    const int sn = (st == 2 ? 0 : st + 1) * STAGE;
+    const int sn = (st == NST - 1 ? 0 : st + 1) * STAGE;
     MFC2_REP12(MFC2_SLOT_A, sb)
     MFC2_WAIT_LGKM0();
-    if (it + 2 < nit) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+    {
+      const int r = nit - 1 - it;    // groups in flight; chunk it+1 must have landed: r - 1 may stay
+      if (r >= 5) { MFC2_WAIT_VM(4 * NL <= 63 ? 4 * NL : 0); } else if (r == 4) { MFC2_WAIT_VM(3 * NL); } else if (r == 3) { MFC2_WAIT_VM(2 * NL); }
+      else if (r == 2) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     MFC2_REP12(MFC2_SLOT_B, sn, false)
-    st = st == 2 ? 0 : st + 1;
+    st = st == NST - 1 ? 0 : st + 1;
   }
 
   // ---- epilogue.  D[cout][pixel]: lane holds pixel (lane & 31) and couts (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32 x 32 block.
@@ -303,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   __builtin_amdgcn_s_barrier();
   constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [pixel][FN couts] fp32 (+16 B: conflict-free b128 writes)
   char* stg = smem + wave * (FM * PITCH);
-  static_assert(8 * FM * PITCH <= 3 * STAGE, "epilogue staging must fit in the pipeline stages");
+  static_assert(8 * FM * PITCH <= NST * STAGE, "epilogue staging must fit in the pipeline stages");
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -312,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv;
+        for (int e = 0; e < 4; ++e) v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out[i];
         *reinterpret_cast<f32x4*>(stg + (i * 32 + (lane & 31)) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
       }
   MFC2_WAIT_LGKM0();   // wave-private region: no barrier needed between the write and the read-back
@@ -325,7 +364,8 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
     b0 = *reinterpret_cast<const f32x4*>(p.bias + col0);
     b1 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4);
   }
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, vmax = 0.f;
+  int vn = -1;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int row = ps * RPP + rr;
@@ -344,12 +384,15 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
       }
       *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0) = v0;
       *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0 + 4) = v1;
-      if (p.ys) {
-        u32x4 hi, lo;
-        split8_f16(v0, v1, hi, lo);
-        u32x4* d = reinterpret_cast<u32x4*>(p.ys) + (orow * (p.Cout >> 3) + (col0 >> 3)) * 2;
-        d[0] = hi;
-        d[1] = lo;
+      if (p.out_bound) {
+        const int n = m / p.HWout;
+        if (n != vn) {   // (a tile inside one sample never gets here twice)
+          if (vn >= 0) atomicMax(p.out_bound + vn, absbits(vmax));
+          vn = n;
+          vmax = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -357,6 +400,15 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
         s2 = fmaf(v0[e], v0[e], s2);
         s2 = fmaf(v1[e], v1[e], s2);
       }
+    }
+  }
+  if (p.out_bound) {
+    const int n0_ = __builtin_amdgcn_readfirstlane(vn);
+    if (__builtin_amdgcn_ballot_w64(vn != n0_) == 0) {   // the wave's rows lie in one sample (or it has none): one atomic
+      vmax = wave_max(vmax);
+      if (lane == 0 && n0_ >= 0) atomicMax(p.out_bound + n0_, absbits(vmax));
+    } else if (vn >= 0) {
+      atomicMax(p.out_bound + vn, absbits(vmax));
     }
   }
   if (p.gn_partial) {  // host guarantees splitk == 1, HWout % BM == 0 (tile inside one sample), BN % cpg == 0, cpg % 8 == 0
@@ -388,11 +440,13 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   }
 }
 
-// fp32 NHWC (any tensor whose innermost extent is a multiple of 8) -> fp16 pairs, 8 channels per thread
-__global__ __launch_bounds__(256) void split_act_f16x2_kernel(const float* __restrict__ x, u32x4* __restrict__ out, long octets) {
+// fp32 [rows][per_row] -> fp16 pairs, 8 consecutive elements per thread; row r is scaled by 2^-scale_exp_of(bound[r]) (bound null: unscaled)
+__global__ __launch_bounds__(256) void split_act_f16x2_kernel(const float* __restrict__ x, u32x4* __restrict__ out, long octets,
+                                                              const float* __restrict__ bound, long octets_per_row) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < octets; o += stride) {
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o * 8), v1 = *reinterpret_cast<const f32x4*>(x + o * 8 + 4);
+    const float sc = bound ? exp2i(-scale_exp_of(bound[o / octets_per_row])) : 1.f;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o * 8) * sc, v1 = *reinterpret_cast<const f32x4*>(x + o * 8 + 4) * sc;
     u32x4 hi, lo;
     split8_f16(v0, v1, hi, lo);
     out[o * 2] = hi;

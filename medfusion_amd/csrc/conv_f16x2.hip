@@ -1,6 +1,7 @@
 // conv_f16x2.hip -- MF_CONV_FP32_F16X2: planner, launch and C-ABI of the fp16-pair implicit-GEMM convolution (kernel: conv_f16x2.h).
 // Replaces torch.nn.Conv2d.forward at conv_blocks.py:185,238,66,123-125 and unet2.py:259 (include/medfusion_hip.h has the call-site map).
 #include "common.h"
+#include <string.h>
 #include "gn_partial.h"
 #include "conv_plan.h"
 #include "conv_f16x2.h"
@@ -13,6 +14,7 @@ namespace {
 struct Tile2 { int id, BM, BN, WM, WN; };
 const Tile2 kTiles2[] = {
     {31, 128, 256, 2, 4}, {32, 256, 128, 4, 2}, {33, 128, 128, 2, 4}, {34, 128, 128, 4, 2}, {35, 256, 64, 4, 2}, {36, 128, 64, 4, 2}, {37, 64, 256, 1, 8},
+    {43, 128, 128, 2, 4}, {46, 128, 64, 4, 2},
 };
 
 struct Plan2 {
@@ -79,12 +81,18 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST>
 int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
-  constexpr size_t lds = 3u * (BM + BN) * 128u;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr size_t lds = (size_t)NST * (BM + BN) * 128u;
+  static bool attr_set[64] = {};   // per device: the attribute belongs to the (function, device) pair
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN>), dim3(grid), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), dim3(grid), dim3(512), lds, s, p);
   return check_launch("conv_f16x2");
 }
 
@@ -133,17 +141,27 @@ int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk)
   return igemm_plan_query(d, tile_id, splitk);
 }
 
-int mf_split_f16x2(const float* x, void* xs, int64_t n, void* stream) {
-  MF_REQUIRE(x && xs && n > 0 && n % 8 == 0, MF_EINVAL, "split_f16x2: bad args (n %% 8 == 0)");
-  const long octets = n / 8;
-  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * n);
+int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64_t per_row, void* stream) {
+  MF_REQUIRE(x && xs && rows > 0 && per_row > 0 && per_row % 8 == 0, MF_EINVAL, "split_f16x2: bad args (per_row %% 8 == 0)");
+  const long octets = (long)rows * (per_row / 8);
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * rows * (double)per_row);
   const int blocks = (int)((octets + 255) / 256 > 8192 ? 8192 : (octets + 255) / 256);
-  hipLaunchKernelGGL(mfc2::split_act_f16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), octets);
+  hipLaunchKernelGGL(mfc2::split_act_f16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), octets, bound,
+                     (long)(per_row / 8));
   return check_launch("split_f16x2");
 }
 
-int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* ys, void* workspace,
-                    size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream) {
+static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of (split_f16.h)
+  if (!(bound > 0.f)) return 0;
+  uint32_t u;
+  memcpy(&u, &bound, 4);
+  const int s = (int)((u >> 23) & 0xffu) - 127 - 14;
+  return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+
+int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
+                    float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d,
+                    void* stream) {
   MF_REQUIRE(d && d->precision == MF_CONV_FP32_F16X2, MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2");
   Plan2 pl;
   int rc = make_plan2(d, &pl);
@@ -154,7 +172,8 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   MF_REQUIRE(!gn_partial || gn_parts2(d, pl, G) > 0, MF_EUNSUPPORTED, "conv(f16x2): cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
   hipStream_t s = (hipStream_t)stream;
   mfc2::ConvP2 p;
-  p.x1 = x1s; p.x2 = x2s; p.w = ws; p.bias = bias; p.y = y; p.ys = ys;
+  p.x1 = x1s; p.x2 = x2s; p.w = ws; p.bias = bias; p.y = y;
+  p.bound1 = x1_bound; p.bound2 = x2_bound; p.wexp = host_scale_exp(w_bound); p.out_bound = reinterpret_cast<unsigned*>(y_bound);
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
   p.Hout = pl.Hout; p.Wout = pl.Wout; p.Heff = pl.Heff; p.Weff = pl.Weff;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -173,37 +192,42 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
     MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);
     p.y = reinterpret_cast<float*>(workspace);
-    p.ys = nullptr;
+    p.out_bound = nullptr;   // the reducer measures
   }
   const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
   {
     ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * 3.0);
     switch (pl.t.id) {
-      case 31: rc = launch_f16x2<128, 256, 2, 4>(p, s); break;
-      case 32: rc = launch_f16x2<256, 128, 4, 2>(p, s); break;
-      case 33: rc = launch_f16x2<128, 128, 2, 4>(p, s); break;
-      case 34: rc = launch_f16x2<128, 128, 4, 2>(p, s); break;
-      case 35: rc = launch_f16x2<256, 64, 4, 2>(p, s); break;
-      case 36: rc = launch_f16x2<128, 64, 4, 2>(p, s); break;
-      case 37: rc = launch_f16x2<64, 256, 1, 8>(p, s); break;
+      case 31: rc = launch_f16x2<128, 256, 2, 4, 3>(p, s); break;
+      case 32: rc = launch_f16x2<256, 128, 4, 2, 3>(p, s); break;
+      case 33: rc = launch_f16x2<128, 128, 2, 4, 5>(p, s); break;
+      case 34: rc = launch_f16x2<128, 128, 4, 2, 5>(p, s); break;
+      case 35: rc = launch_f16x2<256, 64, 4, 2, 4>(p, s); break;
+      case 36: rc = launch_f16x2<128, 64, 4, 2, 6>(p, s); break;
+      case 37: rc = launch_f16x2<64, 256, 1, 8, 4>(p, s); break;
+      case 43: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s); break;   // 3-stage forms of 33 / 36 (pipeline-depth A/B)
+      case 46: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s); break;
       default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
     }
   }
   if (rc) return rc;
   if (pl.splitk > 1) {
     const int HW = p.HWout;
-    ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1 + (ys ? 1 : 0)));
-    if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ fp16-pair copy) in one streaming pass
+    ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
+    if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ measured bound) in one streaming pass
       const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
       hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, GnFinal{}, ys);
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, GnFinal{},
+                         reinterpret_cast<unsigned*>(y_bound));
       return check_launch("splitk_reduce_stats");
     }
-    const long n4 = (long)pl.M * d->Cout / 4;
-    const int blocks = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, n4, d->Cout,
-                       pl.splitk, p.slab, ys);
+    const long p4 = (long)HW * d->Cout / 4;   // float4s per sample
+    int bx = (int)((p4 + 255) / 256);
+    const int cap = cdiv(2048, d->N);
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
+                       pl.splitk, p.slab, reinterpret_cast<unsigned*>(y_bound));
     return check_launch("splitk_reduce");
   }
   return MF_OK;

@@ -40,13 +40,16 @@ inline int fill_geometry(const MfConvDesc* d, Plan* pl) {
 }
 
 
-// split-K reduction: y = sum_z slabs[z] + bias (+ the fp16-pair copy of y)
+// split-K reduction: y = sum_z slabs[z] + bias (+ the measured per-sample max of |y|: out_bound[n], zero on entry).
+// grid (blocks, N): a block row works inside one sample, so the max needs one atomic per wave.
 template <int UNUSED = 0>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
-                                     long n4, int Cout, int splitk, long slab, void* __restrict__ ys) {
+                                     long per_sample4, int Cout, int splitk, long slab, unsigned* __restrict__ out_bound) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    const long e = i * 4;
+  const long base = (long)blockIdx.y * per_sample4;
+  float vmax = 0.f;
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < per_sample4; j += stride) {
+    const long e = (base + j) * 4;
     float4 s = *reinterpret_cast<const float4*>(slabs + e);
     for (int z = 1; z < splitk; ++z) {
       const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * slab + e);
@@ -57,10 +60,13 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     }
     *reinterpret_cast<float4*>(y + e) = s;
-    if (ys) store_split4(ys, e, s.x, s.y, s.z, s.w);
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
+  }
+  if (out_bound) {
+    vmax = wave_max(vmax);
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bound + blockIdx.y, absbits(vmax));
   }
 }
-
 
 // conv_f16x2.hip
 int f16x2_gn_parts(const MfConvDesc* d, int G);

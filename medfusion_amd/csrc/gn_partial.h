@@ -92,7 +92,7 @@ __device__ __forceinline__ void gn_arrive_and_finalize(const GnFinal& f, const d
 template <bool REDUCE>
 __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int HW, int C, int G,
                                                                    int nslabs, long slab, const float* __restrict__ bias, float* __restrict__ y,
-                                                                   const GnFinal fin, void* __restrict__ ys = nullptr) {
+                                                                   const GnFinal fin, unsigned* __restrict__ out_bound = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][Cs][2], then (fused finalize) 2*256 doubles + flag
   const int chunks = gridDim.x, chunk = blockIdx.x, n = blockIdx.y;
   const int Cs = C / gridDim.z, c_off = blockIdx.z * Cs;  // this workgroup's channel slice
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
   const int p0 = chunk * p_per, p1 = min(HW, p0 + p_per);
   const long nbase = (long)n * HW * C;
 
+  float vmax = 0.f;
   for (int c4 = col; c4 < C4; c4 += lanes_per_row) {  // >1 iteration only when C > 1024
     float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     if (phase < rowphases) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
           }
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           *reinterpret_cast<float4*>(y + e) = v;
-          if (ys) store_split4(ys, e, v.x, v.y, v.z, v.w);
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
         s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
         q0 = fmaf(v.x, v.x, q0); q1 = fmaf(v.y, v.y, q1); q2 = fmaf(v.z, v.z, q2); q3 = fmaf(v.w, v.w, q3);
@@ -128,6 +129,10 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
       float* d = sh + ((long)phase * Cs + c4 * 4) * 2;
       d[0] = s0; d[1] = q0; d[2] = s1; d[3] = q1; d[4] = s2; d[5] = q2; d[6] = s3; d[7] = q3;
     }
+  }
+  if (REDUCE && out_bound) {  // measured upper bound of |y| over the sample (operand scale of a following fp16-pair convolution)
+    vmax = wave_max(vmax);
+    if ((tid & 63) == 0) atomicMax(out_bound + n, absbits(vmax));
   }
   __syncthreads();
   const int cpg = C / G, gs = Cs / cpg;  // groups in this slice

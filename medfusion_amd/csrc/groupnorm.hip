@@ -38,13 +38,26 @@ __global__ __launch_bounds__(256) void gn_stats_final_kernel(const double* __res
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// fp16-pair output of the apply pass (MF_CONV_FP32_F16X2 operand): the per-sample scale comes from an upper bound of |out| that the
+// pass derives from its inputs -- |act(gn(x) gamma + beta)| <= bconst = max|gamma| sqrt(group size) + max|beta| (host constant), or
+// x_bound[n] when nothing is normalised, plus the bounds of the residual and of the embedding row -- and publishes as out_bound[n].
+struct GnSplit {
+  void* outs;               // fp16-pair copy of `out`, or null
+  const float* x_bound;     // [N] bound of |x| (used when stats == null), or null
+  const float* res_bound;   // [N] bound of |residual|, or null
+  const float* emb_bound;   // [N] bound of |emb[n][:]|, or null
+  float bconst;
+  float* out_bound;         // [N] written by the pass
+};
+
 // out = act(gn(x)*gamma + beta) + residual + emb[n][c]
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual,
                                                         const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
-                                                        int HW, int C, int G, int act, void* __restrict__ outs) {
+                                                        int HW, int C, int G, int act, const GnSplit sp) {
   const int C4 = C >> 2;
   const int cpg = C / G;
+  const long per4 = (long)HW * C4;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int c4 = (int)(i % C4);
@@ -74,8 +87,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
-    if (outs) store_split4(outs, i * 4, e[0], e[1], e[2], e[3]);
+    if (sp.outs) {
+      const float b = (stats || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
+      store_split4(sp.outs, i * 4, e[0], e[1], e[2], e[3], exp2i(-scale_exp_of(b)));
+      if (i == (long)n * per4) sp.out_bound[n] = b;
+    }
   }
+}
+
+// per-sample max of |x| -> bound[n] (order-preserving unsigned keys; zero on entry).  grid (blocks, N)
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, unsigned* __restrict__ bound, long per_sample4) {
+  const int n = blockIdx.y;
+  const float4* p = reinterpret_cast<const float4*>(x) + (long)n * per_sample4;
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(bound + n, absbits(m));
 }
 
 // Same pass with the statistics FINALIZE fused in: grid (blocks_per_sample, N); every block first turns the P partial
@@ -173,13 +203,18 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
 
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
                     int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream) {
-  return mf_gn_apply_split_f32(x, stats, gamma, beta, residual, emb, emb_stride, out, nullptr, N, HW, C, G, act, stream);
+  return mf_gn_apply_split_f32(x, stats, gamma, beta, residual, emb, emb_stride, out, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, N, HW, C, G, act,
+                               stream);
 }
 
 int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
-                          int64_t emb_stride, float* out, void* out_split, int N, int HW, int C, int G, int act, void* stream) {
+                          int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound, const float* emb_bound,
+                          float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream) {
   MF_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, MF_EINVAL, "gn_apply: bad args");
-  MF_REQUIRE(!out_split || C % 8 == 0, MF_EUNSUPPORTED, "gn_apply: the fp16-pair output needs C %% 8 == 0");
+  MF_REQUIRE(!out_split || (C % 8 == 0 && out_bound), MF_EUNSUPPORTED, "gn_apply: the fp16-pair output needs C %% 8 == 0 and out_bound");
+  MF_REQUIRE(!out_split || stats || x_bound, MF_EINVAL, "gn_apply: the fp16-pair output of an un-normalised pass needs x_bound");
+  MF_REQUIRE(!out_split || !residual || res_bound, MF_EINVAL, "gn_apply: the fp16-pair output needs res_bound with a residual");
+  MF_REQUIRE(!out_split || !emb || emb_bound, MF_EINVAL, "gn_apply: the fp16-pair output needs emb_bound with an embedding");
   MF_REQUIRE(C % 4 == 0, MF_EUNSUPPORTED, "gn_apply: C=%d must be a multiple of 4", C);
   MF_REQUIRE(!stats || (G > 0 && C % G == 0), MF_EINVAL, "gn_apply: C=%d G=%d", C, G);
   MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply: gamma/beta must both be given or both NULL");
@@ -190,9 +225,22 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
   long blocks = (total4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
+  const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
-                     G > 0 ? G : 1, act, out_split);
+                     G > 0 ? G : 1, act, sp);
   return check_launch("gn_apply");
+}
+
+int mf_maxabs_rows_f32(const float* x, float* bound, int N, int64_t per_row, void* stream) {
+  MF_REQUIRE(x && bound && N > 0 && per_row > 0 && per_row % 4 == 0 && N <= 65535, MF_EINVAL, "maxabs_rows: bad args (per_row %% 4 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * N * (double)per_row);
+  const long p4 = per_row / 4;
+  int blocks = (int)((p4 + 1023) / 1024);
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(maxabs_kernel, dim3(blocks, N), dim3(256), 0, s, x, reinterpret_cast<unsigned*>(bound), p4);
+  return check_launch("maxabs_rows");
 }
 
 

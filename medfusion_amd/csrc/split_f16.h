@@ -2,7 +2,11 @@
 //   x ~ hi + lo' / 2048,   hi = RN16(x),   lo' = RN16((x - hi) * 2048)      (the subtraction and the scaling are exact)
 // 23 of the 24 significand bits survive: |x - hi - lo'/2048| <= 2^-23 |x| (one ulp of the fp32 value at most; exact for 3 values of 4).
 // Storage: groups of 8 consecutive channels as 32 bytes [hi x 8][lo' x 8] -- 4 bytes per element, like fp32.
-// Range: |x| <= 65504 (clamped); below 2^-14 the absolute accuracy is 2^-36.
+// Range: fp16 reaches 65504, activations do not stop there (an un-normalised residual stream follows the magnitude of the network input),
+// so every split tensor carries a per-sample power-of-two scale: with `bound[n]` an upper bound of |x| over sample n (measured, or
+// derived from the producing layer), s = floor(log2(bound)) - 14 and the pair stores x * 2^-s, i.e. |x 2^-s| < 2^15.  Scaling by a
+// power of two is exact; values more than 28 binades below the bound keep an absolute accuracy of 2^-50 * bound.  The consuming
+// convolution multiplies its fp32 accumulators by 2^s (per output pixel = per sample), again exactly.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,6 +18,14 @@ typedef unsigned int sf_u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 sf_f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f, kF16Max = 65504.f;
+
+// exponent s of the per-sample scale 2^-s for an upper bound of |x| (0, denormal, inf and NaN bounds are clamped to +-100)
+__device__ __forceinline__ int scale_exp_of(float bound) {
+  const int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127;
+  const int s = e - 14;
+  return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+__device__ __forceinline__ float exp2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }  // 2^s, -126 <= s <= 127
 
 __device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
   a = __builtin_fminf(__builtin_fmaxf(a, -kF16Max), kF16Max);
@@ -35,14 +47,23 @@ __device__ __forceinline__ void split8_f16(const sf_f32x4 v0, const sf_f32x4 v1,
   hi = sf_u32x4{h0, h1, h2, h3};
   lo = sf_u32x4{l0, l1, l2, l3};
 }
-// 4 consecutive channels starting at element index e (a multiple of 4) of a tensor whose innermost extent is a multiple of 8
-__device__ __forceinline__ void store_split4(void* ys, long e, float a, float b, float c, float d) {
+// 4 consecutive channels starting at element index e (a multiple of 4) of a tensor whose innermost extent is a multiple of 8;
+// sc = 2^-s of the sample the element belongs to
+__device__ __forceinline__ void store_split4(void* ys, long e, float a, float b, float c, float d, float sc) {
   unsigned h0, h1, l0, l1;
-  split2_f16(a, b, h0, l0);
-  split2_f16(c, d, h1, l1);
+  split2_f16(a * sc, b * sc, h0, l0);
+  split2_f16(c * sc, d * sc, h1, l1);
   sf_u32x2* o = reinterpret_cast<sf_u32x2*>(ys) + (e >> 3) * 4 + ((e >> 2) & 1);
   o[0] = sf_u32x2{h0, h1};
   o[2] = sf_u32x2{l0, l1};
+}
+
+// |x| as an order-preserving unsigned key (atomicMax on it = running max of non-negative floats)
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
 }
 
 }  // namespace mf

@@ -91,31 +91,67 @@ def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- fp16-pair operands (MF_CONV_FP32_F16X2)
-# The fp16-pair form of an activation travels as an attribute of the fp32 tensor it mirrors (`t._mf_split`, an int32 tensor of the
-# same shape).  Producers that can emit it for free set it (gn_apply(split=True), conv2d_f16x2(split_out=True)); a consumer that
-# does not find it runs the stand-alone split pass once and caches the result on the tensor.  Every wrapper that writes INTO an
-# existing tensor (`out=`) drops a stale mirror first.
+# The fp16-pair form of an activation travels as attributes of the fp32 tensor it mirrors: `t._mf_split` (an int32 tensor of the same
+# shape) and `t._mf_bound` (float [N]: the per-sample upper bound of |t| whose exponent scaled the pairs -- fp16 stops at 65504, an
+# un-normalised residual stream does not; csrc/split_f16.h).  Producers that know a bound for free set both (gn_apply(split=True)); the
+# fp16-pair convolution can MEASURE the bound of its output (measure_out=True); a consumer that finds neither runs the stand-alone
+# passes (max |t| per sample, then the split) once and caches the result on the tensor.  Every wrapper that writes INTO an existing
+# tensor (`out=`) drops stale mirrors first.
 def drop_split(t: Optional[torch.Tensor]) -> None:
-    if t is not None and getattr(t, "_mf_split", None) is not None:
-        t._mf_split = None
+    if t is not None:
+        if getattr(t, "_mf_split", None) is not None:
+            t._mf_split = None
+        if getattr(t, "_mf_bound", None) is not None:
+            t._mf_bound = None
 
 
-def split_f16x2(x: torch.Tensor) -> torch.Tensor:
-    """fp32 tensor (innermost extent % 8 == 0) -> its fp16-pair form, an opaque int32 tensor of the same shape"""
+def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
+    """x [N, ...] contiguous fp32 -> bound [N] = max |x[n]| (measured on the device, no host sync)"""
     _gpu(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("maxabs_rows: contiguous fp32")
+    n = x.shape[0]
+    bound = torch.zeros((n,), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_maxabs_rows_f32(x.data_ptr(), bound.data_ptr(), n, x.numel() // n, stream()), "mf_maxabs_rows_f32")
+    return bound
+
+
+def bound_of(x: torch.Tensor) -> torch.Tensor:
+    b = getattr(x, "_mf_bound", None)
+    if b is None:
+        b = maxabs_rows(x)
+        x._mf_bound = b
+    return b
+
+
+def split_f16x2(x: torch.Tensor, bound: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 tensor [N, ...] (innermost extent % 8 == 0) -> its fp16-pair form, an opaque int32 tensor of the same shape; row n is scaled
+    by the power of two that `bound[n]` implies (None: unscaled)"""
+    _gpu(x, bound)
     if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[-1] % 8:
         raise RuntimeError("split_f16x2: contiguous fp32 with innermost extent % 8 == 0")
+    rows = x.shape[0] if bound is not None else 1
+    if bound is not None and bound.numel() != rows:
+        raise RuntimeError("split_f16x2: one bound per leading index")
     out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
-    L.check(L.load().mf_split_f16x2(x.data_ptr(), out.data_ptr(), x.numel(), stream()), "mf_split_f16x2")
+    L.check(L.load().mf_split_f16x2(x.data_ptr(), out.data_ptr(), _ptr(bound), rows, x.numel() // rows, stream()), "mf_split_f16x2")
     return out
 
 
 def split_of(x: torch.Tensor) -> torch.Tensor:
     s = getattr(x, "_mf_split", None)
     if s is None:
-        s = split_f16x2(x)
+        s = split_f16x2(x, bound_of(x))
         x._mf_split = s
     return s
+
+
+def split_weight_f16x2(w_packed: torch.Tensor):
+    """packed fp32 conv weights -> (fp16-pair form scaled by their own max, that max as a float); load-time work (one host sync)"""
+    w = w_packed.contiguous()
+    wmax = float(w.abs().max().item())
+    bound = torch.full((1,), wmax, dtype=torch.float32, device=w.device)
+    return split_f16x2(w.view(1, -1), bound).view(w.shape), wmax
 
 
 def conv_f16x2_ok(d: L.MfConvDesc) -> bool:
@@ -129,28 +165,30 @@ def conv_plan(d: L.MfConvDesc):
     return t.value, k.value
 
 
-def conv2d_f16x2(x1: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None, split_out: bool = False, gn_groups: int = 0, gn_parts: int = 0):
-    """MF_CONV_FP32_F16X2 convolution of fp32 NHWC tensors whose fp16-pair mirrors are made on demand.
+def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, measure_out: bool = False, gn_groups: int = 0, gn_parts: int = 0):
+    """MF_CONV_FP32_F16X2 convolution of fp32 NHWC tensors whose fp16-pair mirrors are made on demand.  w_split = split_weight_f16x2(...).
+    measure_out: also measure the per-sample max |y| (-> y._mf_bound: the output feeds a convolution or a residual add un-normalised).
     Returns y, or (y, partial [N, parts, G, 2]) when gn_groups > 0 (statistics of the GroupNorm that follows)."""
-    _gpu(x1, x2, w_split, bias)
+    wh, wmax = w_split
+    _gpu(x1, x2, wh, bias)
     lib = L.load()
-    x1s = split_of(x1)
-    x2s = split_of(x2) if x2 is not None else None
+    x1s, b1 = split_of(x1), bound_of(x1)
+    x2s, b2 = (split_of(x2), bound_of(x2)) if x2 is not None else (None, None)
     ho, wo = conv_out_hw(d)
     if out is None:
         out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
     else:
         drop_split(out)
-    ys = torch.empty(out.shape, dtype=torch.int32, device=x1.device) if split_out else None
+    yb = torch.zeros((d.N,), dtype=torch.float32, device=x1.device) if measure_out else None
     partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=x1.device) if gn_groups else None
     need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
-    rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), w_split.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ys), _ptr(ws), need, _ptr(partial),
-                             gn_groups, C.byref(d), stream())
+    rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), wmax, _ptr(yb), _ptr(ws), need,
+                             _ptr(partial), gn_groups, C.byref(d), stream())
     L.check(rc, "mf_conv2d_f16x2")
-    if split_out:
-        out._mf_split = ys
+    if measure_out:
+        out._mf_bound = yb
     return (out, partial) if gn_groups else out
 
 
@@ -320,21 +358,34 @@ def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
 
 
 def gn_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
-             emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None, split: bool = False) -> torch.Tensor:
-    """split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution)"""
+             emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None, split: bool = False,
+             bconst: float = 0.0) -> torch.Tensor:
+    """split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution), scaled per sample
+    by the bound the pass derives: bconst (>= max |act(gn(x) gamma + beta)|, from the caller; the bound of x when nothing is normalised)
+    + the bounds of the residual and of the embedding rows."""
     _gpu(x, stats, gamma, beta, residual, emb)
     n, h, w, c = x.shape
+    split = split and c % 8 == 0
+    xb = rb = eb = ob = outs = None
+    if split:  # (before `out` may alias x or the residual: their bounds describe the values this pass READS)
+        xb = bound_of(x) if stats is None else None
+        rb = bound_of(residual) if residual is not None else None
+        if emb is not None:
+            eb = getattr(emb, "_mf_bound", None)
+            if eb is None:
+                eb = maxabs_rows(emb.contiguous())
     if out is None:
         out = torch.empty_like(x)
     else:
         drop_split(out)
-    split = split and c % 8 == 0
-    outs = torch.empty(out.shape, dtype=torch.int32, device=x.device) if split else None
+    if split:
+        outs = torch.empty(out.shape, dtype=torch.int32, device=x.device)
+        ob = torch.empty((n,), dtype=torch.float32, device=x.device)
     rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
-                                        _ptr(outs), n, h * w, c, G, act, stream())
+                                        _ptr(outs), _ptr(xb), _ptr(rb), _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act, stream())
     L.check(rc, "mf_gn_apply_split_f32")
     if split:
-        out._mf_split = outs
+        out._mf_split, out._mf_bound = outs, ob
     return out
 
 

@@ -188,8 +188,13 @@ class DiffusionPipeline(nn.Module):
             if self.hoist_embeddings and hasattr(est, "can_precompute_embeddings") and est.can_precompute_embeddings():
                 # all timesteps are known: the embedding path leaves the loop (UNet.precompute_embeddings; bit-identical)
                 has_c = est.cond_embedder is not None
-                emb_tab = (est.precompute_embeddings(t_all[:, 0].contiguous()),
-                           est.embedding_columns(condition if has_c else None, B, dev), est.embedding_columns(un_cond if has_c else None, B, dev))
+                used = set()   # labels that occur in this loop (one host read before the loop starts)
+                for lab in (condition, un_cond):
+                    if has_c and lab is not None:
+                        used.update(int(v) for v in lab.reshape(-1).tolist())
+                tab = est.precompute_embeddings(t_all[:, 0].contiguous(), classes=used if has_c else None)
+                emb_tab = (tab, est.embedding_columns(condition if has_c else None, B, dev, tab),
+                           est.embedding_columns(un_cond if has_c else None, B, dev, tab))
             for i in range(len(rev)):
                 pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond,
                                                             emb=None if emb_tab is None else (emb_tab[0], i, emb_tab[1], emb_tab[2]))

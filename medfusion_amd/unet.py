@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from . import lib as L
+from . import blocks as BLK
 from .blocks import (Attention, BasicBlock, BasicDown, BasicUp, Conv, SequentialEmb, UnetBasicBlock, UnetResBlock, _EmbBlock, zero_module)
 
 
@@ -183,11 +184,23 @@ class UNet(nn.Module):
             w, b = self._packed_local_embedders()
             local_all = K.linear(emb, w, b, act_in=True)  # [B, sum Cout]
 
+        rowmax = None
+        if BLK.f16x2_mode():  # operand bound of everything an embedding row is added to (fp16-pair scaling, kernels.gn_apply)
+            rowmax = getattr(local_all, "_mf_bound", None)
+            if rowmax is None:
+                rowmax = K.maxabs_rows(local_all)
+                local_all._mf_bound = rowmax
+
         def lookup(m):
             if isinstance(m, Attention):
                 return emb
             o = self._emb_off.get(id(m))
-            return None if o is None else local_all[:, o[0]:o[0] + o[1]]
+            if o is None:
+                return None
+            v = local_all[:, o[0]:o[0] + o[1]]
+            if rowmax is not None:
+                v._mf_bound = rowmax
+            return v
 
         return emb, lookup
 
@@ -201,33 +214,48 @@ class UNet(nn.Module):
                 and (self.cond_embedder is None or isinstance(self.cond_embedder, LabelEmbedder)))
 
     @torch.no_grad()
-    def precompute_embeddings(self, t_steps: torch.Tensor):
-        """t_steps [S] (the loop's timesteps in loop order) -> table: column 0 = no condition, column 1 + c = class c."""
+    def precompute_embeddings(self, t_steps: torch.Tensor, classes=None):
+        """t_steps [S] (the loop's timesteps in loop order) -> table: column 0 = no condition, column 1 + k = class classes[k].
+        `classes`: the labels that actually occur (condition and un_cond of the loop); None = every class of the embedder.  The table
+        costs S x (1 + len(classes)) rows, so a 1000-class embedder does not build 1001 columns for a batch that uses three."""
         S = t_steps.shape[0]
         time_emb = self.time_embedder(t_steps.to(torch.float32).contiguous())          # [S, E]
         cols = [time_emb]
+        lut = None
         if self.cond_embedder is not None:
             tab = self.cond_embedder.embedding.weight
-            for c in range(tab.shape[0]):
+            classes = list(range(tab.shape[0])) if classes is None else sorted(set(int(c) for c in classes))
+            lut = torch.zeros((tab.shape[0],), dtype=torch.long, device=t_steps.device)
+            for k, c in enumerate(classes):
                 lab = torch.full((S,), c, dtype=torch.long, device=t_steps.device)
                 cols.append(K.embedding_add(tab, lab, time_emb.clone()))
+                lut[c] = 1 + k
         emb = torch.stack(cols, dim=1).contiguous()                                     # [S, NCOL, E]  (plumbing)
         w, b = self._packed_local_embedders()
         local = K.linear(emb.view(S * len(cols), -1), w, b, act_in=True).view(S, len(cols), -1)
-        return {"emb": emb, "local": local, "need_emb": any(isinstance(m, Attention) for m in self.modules())}
+        table = {"emb": emb, "local": local, "need_emb": any(isinstance(m, Attention) for m in self.modules()), "lut": lut}
+        if BLK.f16x2_mode():  # bound of every embedding row, once (operand scaling of the fp16-pair mode)
+            table["local_bound"] = K.maxabs_rows(local.view(S * len(cols), -1)).view(S, len(cols))
+        return table
 
     @staticmethod
-    def embedding_columns(condition, B, device):
-        """row -> column of the precomputed table: 0 without a condition, 1 + label with one"""
+    def embedding_columns(condition, B, device, table=None):
+        """row -> column of the precomputed table: 0 without a condition, else the column of its label"""
         if condition is None:
             return torch.zeros((B,), dtype=torch.long, device=device)
-        return condition.to(device=device, dtype=torch.long).reshape(-1) + 1
+        lab = condition.to(device=device, dtype=torch.long).reshape(-1)
+        if table is not None and table.get("lut") is not None:
+            return table["lut"].index_select(0, lab)
+        return lab + 1
 
     @staticmethod
     def step_embeddings(table, i: int, cols: torch.Tensor):
         """(emb [B,E] | None, local_all [B, sum Cout]) of loop iteration i for rows with table columns `cols` (a gather: plumbing)"""
         emb = table["emb"][i].index_select(0, cols) if table["need_emb"] else None
-        return emb, table["local"][i].index_select(0, cols)
+        local = table["local"][i].index_select(0, cols)
+        if "local_bound" in table:
+            local._mf_bound = table["local_bound"][i].index_select(0, cols)
+        return emb, local
 
     @torch.no_grad()
     def forward_cfg_pair(self, x_t, t, condition, un_cond, emb_cache=None):

@@ -31,7 +31,7 @@ d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_h
 if a.precision == 3:
     wt = K.split_conv_weight(wt)
 if a.precision == 5:
-    wt = K.split_f16x2(wt)
+    wt = K.split_weight_f16x2(wt)
     conv = K.conv2d_f16x2
 else:
     conv = K.conv2d

@@ -68,7 +68,7 @@ def time_conv(x1, x2, w, b, d, reps):
         k = w.data_ptr()
         if k not in _WH:
             _WH.clear()
-            _WH[k] = K.split_f16x2(w)
+            _WH[k] = K.split_weight_f16x2(w)
         wh = _WH[k]
         y = K.conv2d_f16x2(x1, wh, b, d, x2=x2)   # (the activations' fp16-pair mirrors are cached on the tensors by this first call)
         torch.cuda.synchronize()
@@ -129,8 +129,8 @@ def main():
         if not args.quick:
             tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37) if args.precision == 5 else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
-                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
-                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
+                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 43: 128, 46: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
+                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 43: 128, 46: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
                 if ups == 2 and (h * w_) % bm:
                     continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):

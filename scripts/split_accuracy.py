@@ -23,6 +23,6 @@ for n, h, c1, co, k in ((2, 8, 32, 64, 3), (2, 16, 256, 256, 3), (2, 8, 1024, 10
     errs = []
     for mode in (0, 1, 2, 5):
         d = K.make_conv_desc(n, h, h, c1, 0, co, k, 1, k // 2, 0, precision=mode)
-        y = K.nhwc_to_nchw(K.conv2d_f16x2(xd, K.split_f16x2(wp), bd, d) if mode == 5 else K.conv2d(xd, wp, bd, d)).double()
+        y = K.nhwc_to_nchw(K.conv2d_f16x2(xd, K.split_weight_f16x2(wp), bd, d) if mode == 5 else K.conv2d(xd, wp, bd, d)).double()
         errs.append((float((y - want).abs().max() / want.abs().max()), float(((y - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())))
     print(f"{str((n, h, c1, co, k)):34s} " + " ".join(f"{e[0]:9.2e}" for e in errs) + "   rms " + " ".join(f"{e[1]:8.2e}" for e in errs))

@@ -172,3 +172,99 @@ def test_checkpoint_reader_without_lightning(tmp_path):
     for (k, a), (_, b) in zip(pipe.state_dict().items(), src.state_dict().items()):
         assert torch.equal(a, b), k
     assert "medical_diffusion" not in sys.modules
+
+
+# ----------------------------------------------------------------------------- the real checkpoint layout
+CKPT = Path(__file__).resolve().parent / "golden" / "ckpt" / "runs"
+
+
+def _ref_tensors(path):
+    """state_dict of a fixture checkpoint, read with the product's Lightning-free reader"""
+    from medfusion_amd.checkpoint import read_checkpoint
+    return read_checkpoint(path)
+
+
+def test_checkpoint_written_by_the_reference_classes_loads(tmp_path):
+    """tests/golden/ckpt/ was written by the REFERENCE's DiffusionPipeline / VAE through oracle/gen_ckpt_fixture.py: hyper-parameters
+    captured by save_hyperparameters() hold reference class objects, torch.optim.AdamW, torch.nn.L1Loss; the VAE path baked into them is
+    relative to the training cwd (scripts/train_diffusion.py:114); use_ema=True.  Three ways to the nested VAE, one result."""
+    import shutil
+    ck = _ref_tensors(CKPT / "tiny_diffusion" / "last.ckpt")
+    hp, sd = ck["hyper_parameters"], ck["state_dict"]
+    assert isinstance(hp, dict) and hp["noise_estimator"] is M.UNet and hp["latent_embedder"] is M.VAE and hp["noise_scheduler"] is M.GaussianNoiseScheduler
+    assert hp["noise_estimator_kwargs"]["time_embedder"] is M.TimeEmbbeding and hp["noise_estimator_kwargs"]["cond_embedder"] is M.LabelEmbedder
+    assert hp["latent_embedder_checkpoint"] == "runs/tiny_vae/last_vae.ckpt" and hp["use_ema"] is True
+    assert any(k.startswith("ema_model.averaged_model.") for k in sd) and any(k.startswith("latent_embedder.") for k in sd)
+
+    def check(pipe):
+        assert pipe.use_ema and isinstance(pipe.latent_embedder, M.VAE)
+        got = pipe.state_dict()
+        for k, v in sd.items():
+            if k.startswith(("loss_fct", "latent_embedder.perceiver", "latent_embedder.loss")):
+                continue
+            assert torch.equal(got[k], v), k
+        assert not torch.equal(got["noise_estimator.outc.conv.conv.weight"], got["ema_model.averaged_model.outc.conv.conv.weight"])
+
+    # 1. the baked relative path resolved against the checkpoint's own `runs/` tree
+    check(M.DiffusionPipeline.load_from_checkpoint(CKPT / "tiny_diffusion" / "last.ckpt"))
+    # 2. the pipeline checkpoint alone (what usually reaches a sampling box): VAE hyper-parameters inferred from the tensor shapes
+    lone = tmp_path / "last.ckpt"
+    shutil.copy(CKPT / "tiny_diffusion" / "last.ckpt", lone)
+    pipe = M.DiffusionPipeline.load_from_checkpoint(lone)
+    check(pipe)
+    from medfusion_amd.checkpoint import infer_vae_kwargs
+    kw = infer_vae_kwargs({k[len("latent_embedder."):]: v for k, v in sd.items() if k.startswith("latent_embedder.")})
+    assert kw["hid_chs"] == [32, 32, 32, 32] and kw["emb_channels"] == 8 and kw["strides"] == [1, 2, 2, 2] and kw["deep_supervision"] == 1
+    # 3. an explicit path
+    check(M.DiffusionPipeline.load_from_checkpoint(lone, latent_embedder_checkpoint=str(CKPT / "tiny_vae" / "last_vae.ckpt")))
+    # the VAE checkpoint on its own (VAE.load_from_checkpoint of scripts/helpers/sample_latent_embedder.py:50)
+    from medfusion_amd.checkpoint import load_module_from_checkpoint
+    vae = load_module_from_checkpoint(M.VAE, CKPT / "tiny_vae" / "last_vae.ckpt")
+    assert torch.equal(vae.state_dict()["outc.conv.weight"], sd["latent_embedder.outc.conv.weight"])
+
+
+def test_checkpoint_reader_refuses_foreign_globals_and_wrong_architectures(tmp_path):
+    """the unpickler resolves nothing outside its allow-list (a checkpoint is data), and a state dict that does not fit raises"""
+    import pickle
+    from medfusion_amd.checkpoint import load_module_from_checkpoint, read_checkpoint
+    evil = tmp_path / "evil.ckpt"
+    torch.save({"state_dict": {}, "hyper_parameters": {"f": os.system}}, evil)
+    with pytest.raises(pickle.UnpicklingError):
+        read_checkpoint(evil)
+    with pytest.raises(RuntimeError, match="missing"):
+        load_module_from_checkpoint(M.VAE, CKPT / "tiny_vae" / "last_vae.ckpt", deep_supervision=2)   # a head the checkpoint has no weights for
+
+
+def test_seeded_fill_matches_the_test_fill():
+    """medfusion_amd.published.seeded_fill (bench / harness weights) == oracle.synth.synth_state_dict (what the parity tests give the oracle)"""
+    import torch.nn as nn
+    from medfusion_amd import published as P
+    a = nn.Sequential(nn.Conv2d(8, 16, 3), nn.GroupNorm(4, 16), nn.Linear(16, 4), nn.Embedding(3, 4))
+    b = nn.Sequential(nn.Conv2d(8, 16, 3), nn.GroupNorm(4, 16), nn.Linear(16, 4), nn.Embedding(3, 4))
+    S.synth_state_dict(a, "x.embedding.")
+    P.seeded_fill(b, "x.embedding.")
+    for (k, u), (_, v) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(u, v), k
+    assert P.published_unet_kwargs(3)["cond_embedder_kwargs"]["num_classes"] == 3
+    ok, pk = R.published_unet_kwargs(2), P.published_unet_kwargs(2)
+    assert {k: v for k, v in ok.items() if "embedder" not in k} == {k: v for k, v in pk.items() if "embedder" not in k}
+    assert R.published_vae_kwargs(8) == P.published_vae_kwargs(8) and R.published_scheduler_kwargs() == P.published_scheduler_kwargs()
+
+
+def test_default_noise_is_stateful_and_reseedable():
+    """the default Philox source takes a fresh key from torch's CPU generator at every begin(): successive calls differ,
+    torch.manual_seed reproduces them; an explicit seed is a fixed key"""
+    dev = torch.device("cpu")
+    torch.manual_seed(0)
+    a, b = M.PhiloxDeviceNoise(), M.PhiloxDeviceNoise()
+    a.begin(2, dev); b.begin(2, dev)
+    k1, k2 = a._seed, b._seed
+    a.begin(2, dev)
+    assert len({k1, k2, a._seed}) == 3
+    torch.manual_seed(0)
+    c = M.PhiloxDeviceNoise()
+    c.begin(2, dev)
+    assert c._seed == k1
+    e = M.PhiloxDeviceNoise(5)
+    e.begin(2, dev)
+    assert e._seed == 5

@@ -577,24 +577,42 @@ def test_conv_gn_apply_fused_epilogue(dev, shape, prec):
 
 
 # ----------------------------------------------------------------------------- MF_CONV_FP32_F16X2 (fp16 pairs, LDS-DMA kernel)
+def _decode_pairs(xs, shape):
+    """int32 fp16-pair tensor -> float64 hi + lo / 2048 (without the per-sample scale)"""
+    groups = shape[-1] // 8
+    raw = xs.cpu().view(torch.int16).view(*shape[:-1], groups, 2, 8)            # [.., group, piece, 8] fp16 bit patterns
+    hi = raw[..., 0, :].contiguous().view(torch.float16).double().reshape(shape)
+    lo = raw[..., 1, :].contiguous().view(torch.float16).double().reshape(shape)
+    return hi + lo / 2048.0
+
+
 def test_split_f16x2_format(dev):
-    """The fp16-pair form: groups of 8 channels [hi x 8][lo x 8]; hi + lo / 2048 reproduces x to one ulp of its fp32 value
-    (2^-23 |x|: 23 of the 24 significand bits; exact for most values), values past the fp16 range clamp to +-65504, tiny values keep
-    an absolute accuracy of 2^-36."""
+    """The fp16-pair form: groups of 8 channels [hi x 8][lo x 8] of x * 2^-s, s = floor(log2 bound[n]) - 14 per sample;
+    (hi + lo / 2048) * 2^s reproduces x to one ulp of its fp32 value (2^-23 |x|: 23 of the 24 significand bits, exact for most values)
+    at ANY magnitude -- rows of 1e9 and of 1e-9 alike -- and values far below the row's bound keep an absolute accuracy of 2^-50 bound."""
     from medfusion_amd import kernels as K
-    x = _rand("splitx", (3, 5, 7, 64), 3.0)
-    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-7, -3e-9, 70000.0, -1e9, 65504.0, 2.0 ** -14])
-    xs = K.split_f16x2(x.to(dev)).cpu()
-    raw = xs.view(torch.int16).view(3, 5, 7, 8, 2, 8)            # [.., group, piece, 8] fp16 bit patterns
-    hi = raw[..., 0, :].contiguous().view(torch.float16).double().reshape(3, 5, 7, 64)
-    lo = raw[..., 1, :].contiguous().view(torch.float16).double().reshape(3, 5, 7, 64)
-    back = hi + lo / 2048.0
-    ref = x.double().clamp(-65504.0, 65504.0)
+    x = _rand("splitx", (4, 5, 7, 64), 3.0)
+    x[1] *= 1e9                                  # far beyond the fp16 range
+    x[2] *= 1e-9                                 # far below it
+    x[3, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e-7, -3e-9, 1e-12, 2.0 ** -14, 5.0, -5.0])
+    xd = x.to(dev)
+    bound = K.maxabs_rows(xd)
+    assert torch.equal(bound.cpu(), x.abs().amax(dim=(1, 2, 3)))
+    xs = K.split_f16x2(xd, bound)
+    s_exp = torch.floor(torch.log2(bound.cpu().double())) - 14
+    back = _decode_pairs(xs, x.shape) * (2.0 ** s_exp).view(-1, 1, 1, 1)
+    ref = x.double()
     err = (back - ref).abs()
-    assert bool((err <= ref.abs() * 2.0 ** -23 + 2.0 ** -36).all()), float((err / (ref.abs() + 1e-30)).max())
+    tol = ref.abs() * 2.0 ** -23 + (bound.cpu().double() * 2.0 ** -50).view(-1, 1, 1, 1)
+    assert bool((err <= tol).all()), float((err / (ref.abs() + 1e-300)).max())
     assert float((err == 0).double().mean()) > 0.6                                 # three values out of four are exact
-    rms = float(((err[ref.abs() > 1e-3] / ref.abs()[ref.abs() > 1e-3]) ** 2).mean().sqrt())
+    big = ref.abs() > 1e-3 * bound.cpu().double().view(-1, 1, 1, 1)
+    rms = float(((err[big] / ref.abs()[big]) ** 2).mean().sqrt())
     assert rms < 2.0 ** -24, rms                                                   # on average well below one fp32 rounding error
+    # unscaled form (bound = None): identical for a row whose scale exponent is 0
+    x1 = _rand("splitx1", (1, 4, 4, 32), 1.0) * 20000.0
+    b1 = torch.full((1,), 30000.0)
+    assert torch.equal(K.split_f16x2(x1.to(dev), b1.to(dev)), K.split_f16x2(x1.to(dev)))
 
 
 F16X2_CASES = [
@@ -633,7 +651,7 @@ def test_conv_f16x2(dev, case, tile):
     xd = K.nchw_to_nhwc(x.to(dev))
     x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
     wp = K.pack_upconv_weight(wt.to(dev)) if ups == 2 else K.pack_conv_weight(wt.to(dev))
-    wh = K.split_f16x2(wp)
+    wh = K.split_weight_f16x2(wp)
     d0 = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups)
     e0 = relerr(K.nhwc_to_nchw(K.conv2d(xd, wp, b.to(dev), d0, x2=x2d)), want)   # the fp32-MFMA kernel
     cgroups = (c1 + c2) // 32
@@ -642,31 +660,49 @@ def test_conv_f16x2(dev, case, tile):
             continue
         d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=5)
         assert K.conv_f16x2_ok(d), (case, tile, sk)
-        y = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, split_out=True)
+        y = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, measure_out=True)
         e = relerr(K.nhwc_to_nchw(y), want)
         assert e < 1e-5, (case, tile, sk, e, e0)
         assert e < 3 * e0 + 1e-6, (case, tile, sk, e, e0)
-        assert torch.equal(y._mf_split, K.split_f16x2(y)), (case, tile, sk)
+        assert torch.equal(y._mf_bound, y.abs().amax(dim=(1, 2, 3))), (case, tile, sk)      # the measured operand bound of the output
         G = 8
         parts = K.conv_gn_parts(d, G)
         if parts:
             y2, partial = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, gn_groups=G, gn_parts=parts)
             assert torch.equal(y2, y)
-            ref_p, ref_parts = K.gn_stats_partial(y, G)
-            got = partial.sum(1).cpu()
-            ref = ref_p.sum(1).cpu()
-            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6), (case, tile, sk)
+            yg = y.double().cpu().reshape(n, -1, G, co // G)                                 # [N, HW, G, cpg]
+            cnt = yg.shape[1] * yg.shape[3]
+            mean, msq = yg.sum(dim=(1, 3)) / cnt, (yg * yg).sum(dim=(1, 3)) / cnt
+            got = partial.sum(1).cpu() / cnt
+            assert torch.allclose(got[..., 1], msq, rtol=1e-5, atol=0), (case, tile, sk)
+            assert torch.allclose(got[..., 0], mean, rtol=0, atol=1e-5 * float(msq.max().sqrt())), (case, tile, sk)
+    # operands of any magnitude: the same convolution on inputs scaled by 2^40 / 2^-40 per sample gives exactly the scaled result
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, precision=5)
+    y = K.conv2d_f16x2(xd, wh, None, d, x2=x2d)
+    sc = torch.tensor([2.0 ** 40 if i % 2 == 0 else 2.0 ** -40 for i in range(n)], device=dev).view(-1, 1, 1, 1)
+    ys = K.conv2d_f16x2(xd * sc, wh, None, d, x2=None if x2d is None else x2d * sc)
+    assert torch.equal(ys, y * sc), (case, tile)
+    if x2d is not None:   # the two sources of a fused concat carry their own scales
+        yb = K.nhwc_to_nchw(K.conv2d_f16x2(xd * 1024.0, wh, b.to(dev), d, x2=x2d * (1.0 / 4096.0)))
+        wantb = _conv_ref(x * 1024.0, x2 / 4096.0, wt, b, stride, pad, 1 if ups else 0)
+        assert relerr(yb, wantb) < 1e-5, (case, tile)
 
 
 def test_gn_apply_split_mirror(dev):
-    """gn_apply(split=True) writes the fp16-pair mirror of exactly what it writes in fp32"""
+    """gn_apply(split=True) writes the fp16-pair mirror of exactly what it writes in fp32, scaled by the bound it derives and
+    publishes: bconst + bound(residual) + bound(embedding row) >= max |out|"""
     from medfusion_amd import kernels as K
     x = _rand("gas_x", (2, 6, 6, 64)).to(dev)
-    res = _rand("gas_r", (2, 6, 6, 64)).to(dev)
+    res = (_rand("gas_r", (2, 6, 6, 64)) * torch.tensor([1.0, 3e6]).view(2, 1, 1, 1)).to(dev)   # one sample far outside the fp16 range
+    emb = _rand("gas_e", (2, 64)).to(dev)
     gamma, beta = _rand("gas_g", (64,)).to(dev), _rand("gas_b", (64,)).to(dev)
     stats = K.gn_stats(x, 8)
-    y = K.gn_apply(x, stats, gamma, beta, 8, 1, res, split=True)
-    assert torch.equal(y, K.gn_apply(x, stats, gamma, beta, 8, 1, res))
-    assert torch.equal(y._mf_split, K.split_f16x2(y))
-    K.add(y, res, out=y)                      # writing into a tensor drops its (now stale) mirror
-    assert getattr(y, "_mf_split", None) is None
+    bc = float(gamma.abs().max()) * (36 * 8) ** 0.5 + float(beta.abs().max())
+    y = K.gn_apply(x, stats, gamma, beta, 8, 1, res, emb, emb.stride(0), split=True, bconst=bc)
+    assert torch.equal(y, K.gn_apply(x, stats, gamma, beta, 8, 1, res, emb, emb.stride(0)))
+    assert bool((y._mf_bound >= y.abs().amax(dim=(1, 2, 3))).all())
+    want_b = bc + res.abs().amax(dim=(1, 2, 3)) + emb.abs().amax(dim=1)
+    assert torch.allclose(y._mf_bound, want_b, rtol=1e-6)
+    assert torch.equal(y._mf_split, K.split_f16x2(y, y._mf_bound))
+    K.add(y, res, out=y)                      # writing into a tensor drops its (now stale) mirrors
+    assert getattr(y, "_mf_split", None) is None and getattr(y, "_mf_bound", None) is None
