@@ -77,7 +77,8 @@ typedef struct MfConvDesc {
  *   ulp at most, zero for 3 values of 4; the format is 4 bytes per element like fp32, groups of 8 channels as [hi x 8][lo x 8]).  a*b is accumulated in
  *   fp32 as wh*xh + (wh*xl + wl*xh)/2048 -- 3 matrix instructions per product instead of 6, dropped term < 2^-22 |a*b|.  Because the
  *   operands need no arithmetic in the kernel, both go HBM -> LDS by LDS-DMA.  Entry point mf_conv2d_f16x2 (operands produced by
- *   mf_split_f16x2, by the `ys` output of a previous convolution, or by the split output of mf_gn_apply_split_f32).  |x| <= 65504. */
+ *   mf_split_f16x2 or by the split output of mf_gn_apply_split_f32); every operand tensor carries a per-sample power-of-two scale, so
+ *   there is no range limit (mf_gn_apply_split_f32 below has the details). */
 enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4,
        MF_CONV_FP32_F16X2 = 5 };
 
@@ -103,11 +104,13 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
  *   activations no producer kernel has split (rows = N samples).
  * mf_conv2d_f16x2: x1s / x2s / ws in fp16-pair form with their bounds (x*_bound: [N] floats or NULL = unscaled; w_bound: the scalar the
  *   weights were split with, 0 = unscaled); y fp32 NHWC.  gn_partial optional: statistics of the following GroupNorm(G), [N][parts][G][2]
- *   doubles, parts = mf_conv2d_gn_parts(d, G) > 0.  y_bound optional ([N], ZERO on entry): measured max |y| per sample (atomic max), the
- *   operand bound of y for convolutions that consume it un-normalised.  Split-K plans reduce through `workspace`
+ *   doubles, parts = mf_conv2d_gn_parts(d, G) > 0.  y_bound optional ([N][slots] floats, slots = mf_conv2d_f16x2_bound_slots(d) > 0,
+ *   not together with gn_partial): every (tile, wave) -- or reducer wave -- stores the max |y| of its share of a sample; reduce with
+ *   mf_bound_finalize_f32 to the operand bound of y for consumers that take it un-normalised.  Split-K plans reduce through `workspace`
  *   (mf_conv2d_workspace_bytes), the reducer emitting y, the statistics and y_bound.
  * mf_conv2d_plan_query: the tile id and split-K factor the planner picks for `d` (any precision; 0, 0 = not on the implicit-GEMM path). */
 int mf_conv2d_f16x2_ok(const MfConvDesc* d);
+int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d);
 int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64_t per_row, void* stream);
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound,
                     const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, double* gn_partial, int G,
@@ -118,22 +121,8 @@ int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk)
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
  * parts = mf_conv2d_gn_parts(d, G); 0 means this convolution cannot emit them (use mf_gn_stats_partial_f32). */
 int mf_conv2d_gn_parts(const MfConvDesc* d, int G);
-/* gn_stats (+ gn_counter: N int32 that are ZERO on entry and zero again on exit -- allocate zeroed once, reuse): optional FUSED FINALIZE -- the producer workgroup that arrives last for a sample
- * (agent-scope release / per-sample counter / acquire; no spinning) reduces the partial records to stats[n][g] = {mean, rstd},
- * so no separate finalize launch is needed.  NULL, NULL: partial records only. */
 int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* y, void* workspace,
-                     size_t workspace_bytes, double* gn_partial, float* gn_stats, int32_t* gn_counter, int G, float eps,
-                     const MfConvDesc* d, void* stream);
-
-/* Convolution + the WHOLE block epilogue of conv_blocks.py:185-191,236-240,360-363 when the plan splits K: the split-K reducer keeps
- * its values in registers, the workgroups of one (sample, channel slice) meet at an arrival counter, finalize mean/rstd and write
- * out = act(gn(conv) * gamma + beta) + residual + emb -- no un-normalised tensor, no finalize / apply launches.
- * counters: 2 * N * 8 int32, zero on entry, zero again on exit.  parts as for mf_conv2d_gn_f32. */
-int mf_conv2d_gn_apply_ok(const MfConvDesc* d, int G);
-int mf_conv2d_gn_apply_f32(const float* x1, const float* x2, const float* w_packed, const float* bias, float* out, void* workspace,
-                           size_t workspace_bytes, double* gn_partial, int32_t* counters, int G, float eps, const float* gamma,
-                           const float* beta, const float* residual, const float* emb, int64_t emb_stride, int act, const MfConvDesc* d,
-                           void* stream);
+                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm + Swish + residual + embedding
  * Replaces nn.GroupNorm + MONAI Swish + `out + residual` + `x += emb` at conv_blocks.py:186-191,
@@ -143,18 +132,12 @@ int mf_conv2d_gn_apply_f32(const float* x1, const float* x2, const float* w_pack
 size_t mf_gn_stats_workspace_bytes(int N, int HW, int C, int G);
 int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t workspace_bytes, int N, int HW, int C, int G,
                     float eps, void* stream);
-/* Two-kernel form used on the hot path: partial sums [N][parts][G][2] (doubles; parts = mf_gn_partial_parts(HW), or emitted
- * by mf_conv2d_gn_f32), then ONE pass that finalises mean/rstd per workgroup and applies norm+affine+act+residual+emb. */
+/* Form used on the hot path: partial sums [N][parts][G][2] (doubles; parts = mf_gn_partial_parts(HW), or emitted by
+ * mf_conv2d_gn_f32 / mf_conv2d_f16x2), a tiny finalize kernel, then the apply pass. */
 int mf_gn_partial_parts(int HW);
 int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int C, int G, void* stream);
-/* the same pass with the last-arriver finalize fused in: one launch -> stats[n][g] = {mean, rstd} (counter: N int32, zero on entry / zero on exit) */
-int mf_gn_stats_fused_f32(const float* x, double* partial, float* stats, int32_t* counter, int N, int HW, int C, int G, float eps,
-                          void* stream);
 /* partial sums -> stats[n][g] = {mean, rstd} (tiny kernel; measured cheaper than finalising inside every apply workgroup) */
 int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream);
-int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, float eps, const float* gamma, const float* beta,
-                            const float* residual, const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G,
-                            int act, void* stream);
 /* out = act(gn(x) * gamma + beta) + residual + emb[n*emb_stride + c]; act: 0 none, 1 Swish x*sigmoid(x).
  * gamma/beta NULL => no affine; stats NULL => no normalisation; residual / emb NULL => skipped.
  * out may alias x. */
@@ -168,9 +151,14 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
 int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                           const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound,
                           const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
-/* bound[n] = max |x[n][:]| over per_row elements (atomic max: `bound` must be ZERO on entry).  The measured operand bound of tensors no
- * producer bounded analytically (network input convolutions, outputs of convolutions without a GroupNorm, embedding rows). */
-int mf_maxabs_rows_f32(const float* x, float* bound, int N, int64_t per_row, void* stream);
+/* bound[n] = max |x[n][:]| over per_row elements: the measured operand bound of tensors no producer bounded analytically (network
+ * input convolutions, embedding rows).  Two launches, no atomics: every wave stores the max of its share into its own slot of
+ * `partial` (N * mf_maxabs_rows_slots(per_row) floats of caller scratch), then one wave per row reduces the slots.
+ * mf_bound_finalize_f32 is that second pass on its own: it turns the slot array a convolution filled (y_bound of mf_conv2d_f16x2)
+ * into bound[n]. */
+int mf_maxabs_rows_slots(int64_t per_row);
+int mf_maxabs_rows_f32(const float* x, float* partial, float* bound, int N, int64_t per_row, void* stream);
+int mf_bound_finalize_f32(const float* partial, float* bound, int N, int slots, void* stream);
 
 /* ------------------------------------------------------------------ small dense ops
  * mf_linear_f32: y[b*y_stride + o] = sum_i f(x[b*x_stride + i]) * w[o*In + i] + bias[o] (+ y if accumulate);

@@ -87,7 +87,6 @@ class _Packed:
         return self._w3
 
 
-FUSED_GN_FINALIZE = bool(int(os.environ.get("MEDFUSION_FUSED_GN_FINALIZE", "0")))  # see Conv.forward: measured slower than the separate finalize kernel on MI355X
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*):
 #   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
@@ -100,12 +99,6 @@ CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
 
 def f16x2_mode() -> bool:
     return CONV_PRECISION == 5
-APPLY_FROM_PARTIALS = bool(int(os.environ.get("MEDFUSION_APPLY_FROM_PARTIALS", "0")))  # GroupNorm finalize inside the apply pass (A/B switch)
-# conv + GroupNorm + Swish + residual + embedding as ONE launch pair where the plan splits K (mf_conv2d_gn_apply_f32: the reducer keeps its
-# values in registers across a per-(sample, slice) meeting point).  Correct and tested, but measured 3.5 % SLOWER end to end than the
-# separate reducer / finalize / apply launches (20.23 vs 20.96 images/s, same session): all workgroups of a domain wait for its slowest
-# before any of them applies, and the three small kernels each run at full width.  Off; kept as an A/B switch.
-FUSED_GN_EPILOGUE = bool(int(os.environ.get("MEDFUSION_FUSED_GN_EPILOGUE", "0")))
 PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
 
 
@@ -188,57 +181,13 @@ class Conv(nn.Module):
         if not gn_groups:
             return K.conv2d(x1, wp, b, d, x2=x2, out=out)
         ho, wo = K.conv_out_hw(d)
-        if parts > 0:    # statistics fused into the conv epilogue / split-K reducer
-            # finalize: a separate tiny kernel.  The last-arriver fused finalize (FUSED_GN_FINALIZE) is bit-identical but was measured
-            # 0.4 % slower end-to-end: its agent-scope release makes every producer workgroup write back its freshly dirtied L2 lines.
-            y, stats, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2, eps=gn_eps, finalize=FUSED_GN_FINALIZE and not APPLY_FROM_PARTIALS)
-            if stats is None:
-                stats = ("partial", partial, parts, gn_eps) if APPLY_FROM_PARTIALS else K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
-            return y, stats
-        y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
-        if FUSED_GN_FINALIZE and not APPLY_FROM_PARTIALS:
-            return y, K.gn_stats_fused(y, gn_groups, gn_eps)
-        partial, parts = K.gn_stats_partial(y, gn_groups)
-        if APPLY_FROM_PARTIALS:
-            return y, ("partial", partial, parts, gn_eps)
+        if parts > 0:    # statistics fused into the conv epilogue / split-K reducer; finalize: a separate tiny kernel (the fused
+            # last-arriver and in-apply variants of round 1 measured slower and are gone)
+            y, partial = K.conv2d_gn(x1, wp, b, d, gn_groups, parts, x2=x2)
+        else:
+            y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
+            partial, parts = K.gn_stats_partial(y, gn_groups)
         return y, K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
-
-
-def _conv_forward_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, in_layout=L.LAYOUT_NHWC):
-    """conv -> GroupNorm -> act -> + residual -> + emb in one launch pair, or None when this convolution cannot (no split-K plan, ...)."""
-    if not FUSED_GN_EPILOGUE or in_layout != L.LAYOUT_NHWC:
-        return None
-    x1, x2 = _split(x)
-    n, h, w, c1 = x1.shape
-    c2 = 0 if x2 is None else x2.shape[-1]
-    if c1 + c2 != self.in_ch:
-        raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
-    G = norm.num_groups
-    key = ("gn_apply", n, h, w, c1, c2, G, CONV_PRECISION, PRESPLIT_WEIGHTS)
-    ent = self._descs.get(key)
-    if ent is None:
-        d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, self.upsample, precision=CONV_PRECISION)
-        if self.upsample and SUBPIXEL_UPSAMPLE:
-            d2 = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2, precision=CONV_PRECISION)
-            if K.subpixel_ok(d2):
-                d = d2
-        if d.precision == 1 and PRESPLIT_WEIGHTS and K.conv_is_igemm(d):
-            d.precision = 3
-        if d.precision == 4 and not K.conv_is_igemm(d):
-            d.precision = 0
-        ok = K.conv_gn_apply_ok(d, G)
-        ent = (d, K.conv_gn_parts(d, G) if ok else 0, ok)
-        self._descs[key] = ent
-    d, parts, ok = ent
-    if not ok:
-        return None
-    pk = self._packed_sub if d.upsample == 2 else self._packed
-    wp = pk.get_split(self.weight) if d.precision == 3 else pk.get_bf16(self.weight) if d.precision == 4 else pk.get(self.weight)
-    return K.conv2d_gn_apply(x1, wp, self.bias, d, G, parts, norm.weight, norm.bias, x2=x2, eps=norm.eps, act=act, residual=residual, emb=emb,
-                             emb_stride=emb_stride)
-
-
-Conv.forward_gn_apply = _conv_forward_gn_apply
 
 
 class GroupNorm(nn.Module):
@@ -289,9 +238,6 @@ class BasicBlock(nn.Module):
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
-            y = self.conv.forward_gn_apply(x, self.norm, int(self.has_act), residual, emb, emb_stride, in_layout)
-            if y is not None:
-                return y
             return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride)
         y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         if not (self.has_act or residual is not None or emb is not None):
@@ -309,8 +255,6 @@ def _basicblock_conv_and_stats(self, x, in_layout=L.LAYOUT_NHWC):
 def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
     y, stats = y_stats
     nm = self.norm
-    if isinstance(stats, tuple):  # ("partial", records, parts, eps): finalize inside the apply pass
-        return K.gn_apply_partial(y, stats[1], stats[2], nm.weight, nm.bias, nm.num_groups, stats[3], int(self.has_act), residual, emb, emb_stride, out=y)
     split = f16x2_mode()
     bc = nm.bound_const(y.shape[1] * y.shape[2] * (y.shape[3] // nm.num_groups)) if split else 0.0
     return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=split, bconst=bc)

@@ -415,45 +415,19 @@ size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
   return (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
 }
 
-struct GnOut { double* partial; float* stats; int32_t* counter; int G; float eps; const GnApplyArgs* apply = nullptr; };
+struct GnOut { double* partial; int G; };
 static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
                        const GnOut& gn, const MfConvDesc* d, void* stream);
 
 int mf_conv2d_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
                   size_t workspace_bytes, const MfConvDesc* d, void* stream) {
-  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{nullptr, nullptr, nullptr, 0, 0.f}, d, stream);
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{nullptr, 0}, d, stream);
 }
 
 int mf_conv2d_gn_f32(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace,
-                     size_t workspace_bytes, double* gn_partial, float* gn_stats, int32_t* gn_counter, int G, float eps, const MfConvDesc* d,
-                     void* stream) {
+                     size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d, void* stream) {
   MF_REQUIRE(gn_partial && mf_conv2d_gn_parts(d, G) > 0, MF_EUNSUPPORTED, "conv_gn: this convolution cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
-  MF_REQUIRE((gn_stats == nullptr) == (gn_counter == nullptr), MF_EINVAL, "conv_gn: gn_stats and gn_counter go together");
-  MF_REQUIRE(G <= 256, MF_EUNSUPPORTED, "conv_gn: G > 256");
-  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{gn_partial, gn_stats, gn_counter, G, eps}, d, stream);
-}
-
-/* 1 if mf_conv2d_gn_apply_f32 can run `d` followed by GroupNorm(G): the plan splits K (there is a reducer to fuse into) and a
- * reducer thread can carry its share of the tensor in registers */
-int mf_conv2d_gn_apply_ok(const MfConvDesc* d, int G) {
-  Plan pl;
-  if (!d || make_plan(d, &pl) != MF_OK || !pl.igemm || pl.splitk <= 1) return 0;
-  return fused_apply_ok(d->N, pl.Hout * pl.Wout, d->Cout, G) ? 1 : 0;
-}
-
-int mf_conv2d_gn_apply_f32(const float* x1, const float* x2, const float* w, const float* bias, float* out, void* workspace, size_t workspace_bytes,
-                           double* gn_partial, int32_t* counters, int G, float eps, const float* gamma, const float* beta, const float* residual,
-                           const float* emb, int64_t emb_stride, int act, const MfConvDesc* d, void* stream) {
-  MF_REQUIRE(out && gn_partial && counters && mf_conv2d_gn_apply_ok(d, G), MF_EUNSUPPORTED,
-             "conv_gn_apply: needs a split-K plan and a tensor share that fits a reducer thread's registers (ask mf_conv2d_gn_apply_ok)");
-  MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "conv_gn_apply: gamma/beta must both be given or both NULL");
-  MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "conv_gn_apply: emb_stride must be a multiple of 4");
-  Plan pl;
-  (void)make_plan(d, &pl);
-  const int slices = stats_slices(d->N, pl.Hout * pl.Wout, d->Cout, G);
-  GnApplyArgs a{gamma, beta, residual, emb, (long)emb_stride, out, counters, counters + (long)d->N * slices, 0.0, eps, act};
-  GnOut gn{gn_partial, nullptr, nullptr, G, eps, &a};
-  return conv2d_impl(x1, x2, w, bias, out, workspace, workspace_bytes, gn, d, stream);
+  return conv2d_impl(x1, x2, w, bias, y, workspace, workspace_bytes, GnOut{gn_partial, G}, d, stream);
 }
 
 static int conv2d_impl(const float* x1, const float* x2, const float* w, const float* bias, float* y, void* workspace, size_t workspace_bytes,
@@ -484,15 +458,9 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.gn_partial = gn_partial; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 1;
   p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
-  p.gn_fin = GnFinal{};
   p.fastg = (p.ups == 0 && (long)d->N * d->Hin * d->Win < (1L << 24) && d->C1 < (1 << 22) && d->C2 < (1 << 22)) ? 1 : 0;
   static const bool generic_gather = getenv("MF_CONV_GENERIC_GATHER") != nullptr;  // A/B switch (scripts), read once
   if (generic_gather) p.fastg = 0;
-  const int HWo = pl.Hout * pl.Wout;
-  if (gn.stats) {  // last-arriver finalize (gn.counter: zero on entry, zero again on exit)
-    if (pl.igemm && pl.splitk == 1)
-      p.gn_fin = GnFinal{gn.stats, gn.counter, (HWo / pl.cfg.BM) * (d->Cout / pl.cfg.BN), HWo / pl.cfg.BM, (double)HWo * (d->Cout / G), gn.eps};
-  }
   // algorithmic FLOPs of the reference op (the sub-pixel form does 4/9 of the MACs of nearest-x2 + 3x3)
   const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
@@ -616,23 +584,12 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   }
   if (rc) return rc;
   if (pl.splitk > 1) {
-    if (gn_partial && gn.apply) {  // reduction + bias + statistics + finalize + norm/act/residual/embedding: one kernel, values kept in registers
-      const int HW = pl.Hout * pl.Wout;
-      ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1 + (gn.apply->residual ? 1 : 0)));
-      const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW), Cs = d->Cout / slices;
-      GnApplyArgs a = *gn.apply;
-      a.count = (double)HW * (d->Cout / G);
-      hipLaunchKernelGGL(gn_reduce_apply_kernel<0>, dim3(chunks, d->N, slices), dim3(kStatsThreads), fused_apply_lds_bytes(Cs, chunks, Cs / (d->Cout / G)), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, a);
-      return check_launch("splitk_reduce_gn_apply");
-    }
     if (gn_partial) {  // reduction + bias + GroupNorm partial statistics in one streaming pass
       const int HW = pl.Hout * pl.Wout;
       ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
       const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
-      const GnFinal fin = gn.stats ? GnFinal{gn.stats, gn.counter, chunks * slices, chunks, (double)HW * (d->Cout / G), gn.eps} : GnFinal{};
       hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, fin);
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y);
       return check_launch("splitk_reduce_stats");
     }
     const long p4 = (long)pl.Hout * pl.Wout * d->Cout / 4;   // float4s per sample
@@ -641,7 +598,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     const int cap = cdiv(2048, d->N);
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
-                       pl.splitk, p.slab, (unsigned*)nullptr);
+                       pl.splitk, p.slab, (float*)nullptr);
     return check_launch("splitk_reduce");
   }
   return MF_OK;

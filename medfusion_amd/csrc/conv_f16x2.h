@@ -43,7 +43,8 @@ struct ConvP2 {
   const float* bound1;   // [N] per-sample bounds the sources were scaled with (split_f16.h), or null = unscaled
   const float* bound2;
   int wexp;              // the weights were split as w * 2^-wexp
-  unsigned* out_bound;   // optional [N]: measured max |y| per sample (atomic max, zero on entry; splitk == 1)
+  float* out_bound;      // optional [N][slots]: measured max |y| of every (tile, wave) of a sample (splitk == 1, a tile inside one sample)
+  int bound_slots;
   int N, Hin, Win, C1, C2, Cin, Cout;
   int Hout, Wout, Heff, Weff, KH, KW, stride, pad;
   int M, K, HWout;
@@ -67,17 +68,18 @@ __device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; b
 #define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
-  static_assert(WM * WN == 8, "8 waves");
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP2 p) {
+  constexpr int NW = WM * WN;   // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU: independent barrier cadences)
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves");
   constexpr int FM = BM / WM, FN = BN / WN, TM = FM / 32, TN = FN / 32;
   static_assert(TM >= 1 && TN >= 1 && FM % 32 == 0 && FN % 32 == 0, "per-wave footprint");
-  constexpr int GP = BM / 64, GQ = BN / 64, NL = GP + GQ;   // DMA instructions per wave and chunk (8 rows x 128 B each)
-  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile");
+  constexpr int GP = BM / (8 * NW), GQ = BN / (8 * NW), NL = GP + GQ;   // DMA instructions per wave and chunk (8 rows x 128 B each)
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile");
   constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
   constexpr int NM = 3 * TM * TN;                           // MFMAs per 16-deep step
   constexpr int NR = 2 * (TM + TN);                         // fragment reads per step
   constexpr int NF = (2 * NM + 2) / 3;                      // the reads of a step are issued behind its first NF MFMAs (the rest cover their latency)
-  static_assert(NST >= 3 && NST <= 6 && NST * STAGE <= 160 * 1024 && (NST - 1) * NL <= 63, "LDS stages");
+  static_assert(NST >= 2 && NST <= 6 && NST * STAGE <= 160 * 1024 && (NST - 1) * NL <= 63, "LDS stages");
   static_assert((NR + NF - 1) / NF <= 2, "at most two reads per slot");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -98,14 +100,14 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   const int taps = p.KH * p.KW;
   const int nit = (cg_end - cg_beg) * taps;
 
-  // ---- DMA addressing.  Instruction i of this wave moves tile rows 8 (wave + 8 i) + (lane >> 3); LDS slot (lane & 7) of a row holds
+  // ---- DMA addressing.  Instruction i of this wave moves tile rows 8 (wave + NW i) + (lane >> 3); LDS slot (lane & 7) of a row holds
   // source slot (lane & 7) ^ key, key = (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7 for every i.
   const int lrow = lane >> 3;
   const unsigned slot16 = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);
   int a_pix[GP], a_inv[GP];
 #pragma unroll
   for (int i = 0; i < GP; ++i) {
-    const int m = m0 + 8 * (wave + 8 * i) + lrow;
+    const int m = m0 + 8 * (wave + NW * i) + lrow;
     int n_ = 0, iy0 = -(1 << 28), ix0 = 0;   // rows past M: every tap "outside"
     if (m < p.M) {
       const int n = m / p.HWout;
@@ -160,12 +162,12 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
     if constexpr (u_ < GP) {                                                                                            \
       const unsigned tapb_ = (unsigned)(l_ky * p.Win + l_kx) * l_cs4;                                                   \
       const unsigned off_ = (pbase[u_] + tapb_) | (unsigned)__builtin_amdgcn_sbfe(a_inv[u_], (unsigned)(l_ky * p.KW + l_kx), 1u); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + (wave + 8 * u_) * 1024), \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + (wave + NW * u_) * 1024), \
                                                16, off_, 0, 0, 0);                                                      \
     } else {                                                                                                            \
       constexpr int q_ = u_ - GP;                                                                                       \
-      const unsigned so_ = (unsigned)((l_ky * p.KW + l_kx) * p.Cin + l_cc * 32) * 4u + (unsigned)q_ * 64u * kbytes;     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + BM * ROWB + (wave + 8 * q_) * 1024), \
+      const unsigned so_ = (unsigned)((l_ky * p.KW + l_kx) * p.Cin + l_cc * 32) * 4u + (unsigned)q_ * (8u * NW) * kbytes;     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + BM * ROWB + (wave + NW * q_) * 1024), \
                                                16, qv, so_, 0, 0);                                                      \
     }                                                                                                                   \
   }
@@ -212,24 +214,23 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
 
   f16x8 fx[2][TM][2], fw[2][TN][2];   // [step][sub-tile][piece]
 
-  // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source
+  // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source.  The exponents are
+  // re-derived from the bound arrays where they are needed (the source switch, the epilogue): nothing is kept live through the loop.
   const bool first_src1 = cg_beg * 32 < p.C1, last_src2 = (cg_end - 1) * 32 >= p.C1;
   const int it_sw = (first_src1 && last_src2) ? (p.C1 / 32 - cg_beg) * taps : -1;   // first iteration that reads the second source
-  float f_sw[TM], f_out[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int pm = min(m0 + wm * FM + i * 32 + (lane & 31), p.M - 1);
-    const int n = pm / p.HWout;
-    const int e1 = p.bound1 ? scale_exp_of(p.bound1[n]) : 0;
-    const int e2 = (p.bound2 && p.C2 > 0) ? scale_exp_of(p.bound2[n]) : 0;
-    f_sw[i] = exp2i(e1) * exp2i(-e2);
-    f_out[i] = exp2i(last_src2 ? e2 : e1) * exp2i(p.wexp);
-  }
+#define MFC2_PIXEL_EXPS(I)                                                                                              \
+    const int pm_ = min(m0 + wm * FM + (I) * 32 + (lane & 31), p.M - 1);                                                \
+    const int pn_ = pm_ / p.HWout;                                                                                      \
+    const int e1_ = p.bound1 ? scale_exp_of(p.bound1[pn_]) : 0;                                                         \
+    const int e2_ = (p.bound2 && p.C2 > 0) ? scale_exp_of(p.bound2[pn_]) : 0;
 #define MFC2_SOURCE_SWITCH()                                                                                            \
   if (__builtin_expect(it == it_sw, 0)) {                                                                               \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                    \
+      MFC2_PIXEL_EXPS(i)                                                                                                \
+      const float f_ = exp2i(e1_) * exp2i(-e2_);                                                                        \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                                    \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) { accm[i][j][r] *= f_sw[i]; accx[i][j][r] *= f_sw[i]; }          \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) { accm[i][j][r] *= f_; accx[i][j][r] *= f_; }                    \
+    }                                                                                                                   \
   }
 
 // fragment read U (0 .. NR-1) of step S from the stage at byte offset SB
@@ -340,22 +341,10 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
   // All DMA has landed (the last iterations wait vmcnt(0)); the stages are dead once every wave has left the loop.
   MFC2_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
-  constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [pixel][FN couts] fp32 (+16 B: conflict-free b128 writes)
-  char* stg = smem + wave * (FM * PITCH);
-  static_assert(8 * FM * PITCH <= NST * STAGE, "epilogue staging must fit in the pipeline stages");
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out[i];
-        *reinterpret_cast<f32x4*>(stg + (i * 32 + (lane & 31)) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
-      }
-  MFC2_WAIT_LGKM0();   // wave-private region: no barrier needed between the write and the read-back
-  constexpr int LPR = FN / 8, RPP = 64 / LPR, NPASS = FM / RPP;   // lanes per pixel row (8 couts each), rows per pass
+  constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [32 pixels][FN couts] fp32 (+16 B: conflict-free b128 writes)
+  char* stg = smem + wave * (32 * PITCH);
+  static_assert(NW * 32 * PITCH <= NST * STAGE, "epilogue staging must fit in the pipeline stages");
+  constexpr int LPR = FN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;   // lanes per pixel row (8 couts each), rows per pass, passes per sub-tile
   const int rr = lane / LPR, c8 = lane % LPR;
   const int col0 = n0 + wn * FN + c8 * 8;
   float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
@@ -365,55 +354,58 @@ __global__ __launch_bounds__(512, 2) void conv_f16x2_kernel(const ConvP2 p) {
     b1 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4);
   }
   float s1 = 0.f, s2 = 0.f, vmax = 0.f;
-  int vn = -1;
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int row = ps * RPP + rr;
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32 + 16);
-    v0 += b0;
-    v1 += b1;
-    const int m = m0 + wm * FM + row;
-    if (m < p.M) {
-      long orow = m;
-      if (p.subpix) {  // row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
-        const int n = m / p.HWout, rem = m - n * p.HWout;
-        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
-        const int y = r2 / p.Win, x = r2 - y * p.Win;
-        orow = ((long)n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+  for (int i = 0; i < TM; ++i) {   // one 32-pixel sub-tile at a time through the wave's staging region (LDS operations of a wave stay in order)
+    MFC2_PIXEL_EXPS(i)
+    const float f_out = exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out;
+        *reinterpret_cast<f32x4*>(stg + (lane & 31) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
       }
-      *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0) = v0;
-      *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0 + 4) = v1;
-      if (p.out_bound) {
-        const int n = m / p.HWout;
-        if (n != vn) {   // (a tile inside one sample never gets here twice)
-          if (vn >= 0) atomicMax(p.out_bound + vn, absbits(vmax));
-          vn = n;
-          vmax = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + rr;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32);
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32 + 16);
+      v0 += b0;
+      v1 += b1;
+      const int m = m0 + wm * FM + i * 32 + row;
+      if (m < p.M) {
+        long orow = m;
+        if (p.subpix) {  // row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
+          const int n = m / p.HWout, rem = m - n * p.HWout;
+          const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
+          const int y = r2 / p.Win, x = r2 - y * p.Win;
+          orow = ((long)n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
+        }
+        *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0) = v0;
+        *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0 + 4) = v1;
+        if (p.out_bound) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s1 += v0[e] + v1[e];
-        s2 = fmaf(v0[e], v0[e], s2);
-        s2 = fmaf(v1[e], v1[e], s2);
+        for (int e = 0; e < 4; ++e) {
+          s1 += v0[e] + v1[e];
+          s2 = fmaf(v0[e], v0[e], s2);
+          s2 = fmaf(v1[e], v1[e], s2);
+        }
       }
     }
   }
-  if (p.out_bound) {
-    const int n0_ = __builtin_amdgcn_readfirstlane(vn);
-    if (__builtin_amdgcn_ballot_w64(vn != n0_) == 0) {   // the wave's rows lie in one sample (or it has none): one atomic
-      vmax = wave_max(vmax);
-      if (lane == 0 && n0_ >= 0) atomicMax(p.out_bound + n0_, absbits(vmax));
-    } else if (vn >= 0) {
-      atomicMax(p.out_bound + vn, absbits(vmax));
-    }
+  if (p.out_bound) {   // host guarantees HWout % BM == 0: slot ((tile inside the sample), n-tile, wave) of the tile's sample
+    vmax = wave_max(vmax);
+    const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
+    if (lane == 0) p.out_bound[(long)n * p.bound_slots + (part * p.tiles_n + tile_n) * NW + wave] = vmax;
   }
   if (p.gn_partial) {  // host guarantees splitk == 1, HWout % BM == 0 (tile inside one sample), BN % cpg == 0, cpg % 8 == 0
     __builtin_amdgcn_s_barrier();   // every wave has finished with its staging region
-    float* red = reinterpret_cast<float*>(smem);   // [8 waves][64 lanes][2]
+    float* red = reinterpret_cast<float*>(smem);   // [NW waves][64 lanes][2]
     red[(wave * 64 + lane) * 2] = s1;
     red[(wave * 64 + lane) * 2 + 1] = s2;
     MFC2_WAIT_LGKM0();

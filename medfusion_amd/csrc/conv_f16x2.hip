@@ -11,11 +11,14 @@ using namespace mf;
 namespace {
 
 // ------------------------------------------------------------------ MF_CONV_FP32_F16X2: planning and launch (kernel: conv_f16x2.h)
-struct Tile2 { int id, BM, BN, WM, WN; };
+struct Tile2 { int id, BM, BN, WM, WN, NST; };   // LDS per workgroup = NST * (BM + BN) * 128 bytes; <= 80 KB: two workgroups per CU
 const Tile2 kTiles2[] = {
-    {31, 128, 256, 2, 4}, {32, 256, 128, 4, 2}, {33, 128, 128, 2, 4}, {34, 128, 128, 4, 2}, {35, 256, 64, 4, 2}, {36, 128, 64, 4, 2}, {37, 64, 256, 1, 8},
-    {43, 128, 128, 2, 4}, {46, 128, 64, 4, 2},
+    {31, 128, 256, 2, 4, 3}, {32, 256, 128, 4, 2, 3}, {33, 128, 128, 2, 4, 3}, {34, 128, 128, 4, 2, 3}, {35, 256, 64, 4, 2, 3}, {36, 128, 64, 4, 2, 3},
+    {37, 64, 256, 1, 8, 3},
+    // 4-wave workgroups, two per CU (independent barrier cadences on the two waves of a SIMD)
+    {51, 128, 128, 2, 2, 2}, {52, 128, 128, 2, 2, 3}, {53, 64, 128, 2, 2, 3}, {54, 128, 64, 2, 2, 3},
 };
+inline int wgs_per_cu(const Tile2& t) { return (size_t)t.NST * (t.BM + t.BN) * 128 <= 80 * 1024 ? 2 : 1; }
 
 struct Plan2 {
   bool ok;
@@ -69,9 +72,10 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   if (d->splitk_hint > 0) {
     sk = d->splitk_hint;
   } else {
-    // one workgroup per CU (>= 96 KB of LDS): top the grid up to one wave of 256 workgroups; a slice keeps >= 18 chunk iterations
+    // top the grid up to one wave of workgroups (256 CUs x 1 or 2 per CU by LDS); a slice keeps >= 18 chunk iterations
     const int min_cg = pl->taps >= 4 ? 2 : 8;
-    while (tiles * sk * 2 <= 256 && pl->cgroups / (sk * 2) >= min_cg && sk < 16) sk *= 2;
+    const long wave = 256L * wgs_per_cu(*c);
+    while (tiles * sk * 2 <= wave && pl->cgroups / (sk * 2) >= min_cg && sk < 16) sk *= 2;
     // the matrix core adds its 16 products and the accumulator with truncation: keep one accumulation chain <= 96 chunks
     while ((pl->cgroups / sk) * pl->taps > 96 && pl->cgroups / (sk * 2) >= 1 && sk < 32) sk *= 2;
   }
@@ -92,7 +96,7 @@ int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), dim3(grid), dim3(512), lds, s, p);
+  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_f16x2");
 }
 
@@ -126,6 +130,24 @@ extern "C" {
 int mf_conv2d_f16x2_ok(const MfConvDesc* d) {
   Plan2 pl;
   return d && d->precision == MF_CONV_FP32_F16X2 && make_plan2(d, &pl) == MF_OK && pl.ok ? 1 : 0;
+}
+
+// slots of the measured-bound array a conv writes per sample (0: it cannot measure -- a tile straddles two samples)
+static int bound_slots2(const MfConvDesc* d, const Plan2& pl, bool with_stats) {
+  const int HW = pl.Hout * pl.Wout;
+  if (pl.splitk == 1) return HW % pl.t.BM ? 0 : (HW / pl.t.BM) * (d->Cout / pl.t.BN) * (pl.t.WM * pl.t.WN);
+  if (with_stats) return 0;   // (every convolution followed by a GroupNorm is bounded by the normalisation, not by measurement)
+  const long p4 = (long)HW * d->Cout / 4;
+  int bx = (int)((p4 + 255) / 256);
+  const int cap = cdiv(2048, d->N);
+  if (bx > cap) bx = cap;
+  return bx * 4;
+}
+
+int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d) {
+  Plan2 pl;
+  if (!d || d->precision != MF_CONV_FP32_F16X2 || make_plan2(d, &pl) != MF_OK || !pl.ok) return 0;
+  return bound_slots2(d, pl, false);
 }
 
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk) {
@@ -170,10 +192,12 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   MF_REQUIRE(x1s && ws && y, MF_EINVAL, "conv(f16x2): null pointer");
   MF_REQUIRE(d->C2 == 0 || x2s != nullptr, MF_EINVAL, "conv(f16x2): C2 > 0 but x2 is null");
   MF_REQUIRE(!gn_partial || gn_parts2(d, pl, G) > 0, MF_EUNSUPPORTED, "conv(f16x2): cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
+  MF_REQUIRE(!y_bound || (!gn_partial && bound_slots2(d, pl, false) > 0), MF_EUNSUPPORTED,
+             "conv(f16x2): cannot measure the output bound of this plan (mf_conv2d_f16x2_bound_slots == 0, or GroupNorm statistics requested)");
   hipStream_t s = (hipStream_t)stream;
   mfc2::ConvP2 p;
   p.x1 = x1s; p.x2 = x2s; p.w = ws; p.bias = bias; p.y = y;
-  p.bound1 = x1_bound; p.bound2 = x2_bound; p.wexp = host_scale_exp(w_bound); p.out_bound = reinterpret_cast<unsigned*>(y_bound);
+  p.bound1 = x1_bound; p.bound2 = x2_bound; p.wexp = host_scale_exp(w_bound); p.out_bound = y_bound; p.bound_slots = y_bound ? bound_slots2(d, pl, false) : 0;
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
   p.Hout = pl.Hout; p.Wout = pl.Wout; p.Heff = pl.Heff; p.Weff = pl.Weff;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -201,13 +225,15 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     switch (pl.t.id) {
       case 31: rc = launch_f16x2<128, 256, 2, 4, 3>(p, s); break;
       case 32: rc = launch_f16x2<256, 128, 4, 2, 3>(p, s); break;
-      case 33: rc = launch_f16x2<128, 128, 2, 4, 5>(p, s); break;
-      case 34: rc = launch_f16x2<128, 128, 4, 2, 5>(p, s); break;
-      case 35: rc = launch_f16x2<256, 64, 4, 2, 4>(p, s); break;
-      case 36: rc = launch_f16x2<128, 64, 4, 2, 6>(p, s); break;
-      case 37: rc = launch_f16x2<64, 256, 1, 8, 4>(p, s); break;
-      case 43: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s); break;   // 3-stage forms of 33 / 36 (pipeline-depth A/B)
-      case 46: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s); break;
+      case 33: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s); break;
+      case 34: rc = launch_f16x2<128, 128, 4, 2, 3>(p, s); break;
+      case 35: rc = launch_f16x2<256, 64, 4, 2, 3>(p, s); break;
+      case 36: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s); break;
+      case 37: rc = launch_f16x2<64, 256, 1, 8, 3>(p, s); break;
+      case 51: rc = launch_f16x2<128, 128, 2, 2, 2>(p, s); break;
+      case 52: rc = launch_f16x2<128, 128, 2, 2, 3>(p, s); break;
+      case 53: rc = launch_f16x2<64, 128, 2, 2, 3>(p, s); break;
+      case 54: rc = launch_f16x2<128, 64, 2, 2, 3>(p, s); break;
       default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
     }
   }
@@ -218,8 +244,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ measured bound) in one streaming pass
       const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
       hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, GnFinal{},
-                         reinterpret_cast<unsigned*>(y_bound));
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, (float*)nullptr);
       return check_launch("splitk_reduce_stats");
     }
     const long p4 = (long)HW * d->Cout / 4;   // float4s per sample
@@ -227,7 +252,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     const int cap = cdiv(2048, d->N);
     if (bx > cap) bx = cap;
     hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
-                       pl.splitk, p.slab, reinterpret_cast<unsigned*>(y_bound));
+                       pl.splitk, p.slab, y_bound);
     return check_launch("splitk_reduce");
   }
   return MF_OK;

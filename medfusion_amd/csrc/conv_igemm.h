@@ -40,7 +40,6 @@ struct ConvP {
   int subpix, hw_src;               // sub-pixel form of nearest-x2 + 3x3: 4 phase-specific 2x2 convs on the low-res source
   double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
   int gn_groups, gn_parts, gn_cpg;
-  GnFinal gn_fin;                   // optional last-arriver finalize -> stats[n][g] = {mean, rstd}
   int fastg;                        // fast gather usable: no fused nearest-x2 gather, < 2^24 source pixels, < 2^22 channels per source
 };
 
@@ -640,11 +639,6 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
       o[0] = s;
       o[1] = q;
-    }
-    if (p.gn_fin.stats) {
-      __syncthreads();  // chs[] consumed
-      double* red = reinterpret_cast<double*>(smem);  // 2*NT doubles + flag: far below the tile buffers' size
-      gn_arrive_and_finalize(p.gn_fin, p.gn_partial, m0 / p.HWout, p.gn_groups, reinterpret_cast<volatile int*>(red + 2 * NT), red);
     }
   }
 }

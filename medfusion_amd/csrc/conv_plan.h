@@ -40,11 +40,11 @@ inline int fill_geometry(const MfConvDesc* d, Plan* pl) {
 }
 
 
-// split-K reduction: y = sum_z slabs[z] + bias (+ the measured per-sample max of |y|: out_bound[n], zero on entry).
-// grid (blocks, N): a block row works inside one sample, so the max needs one atomic per wave.
+// split-K reduction: y = sum_z slabs[z] + bias (+ the measured max of |y|: slot (block, wave) of out_bound[n][gridDim.x * 4]).
+// grid (blocks, N): a block row works inside one sample.
 template <int UNUSED = 0>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bias, float* __restrict__ y,
-                                     long per_sample4, int Cout, int splitk, long slab, unsigned* __restrict__ out_bound) {
+                                     long per_sample4, int Cout, int splitk, long slab, float* __restrict__ out_bound) {
   const long stride = (long)gridDim.x * blockDim.x;
   const long base = (long)blockIdx.y * per_sample4;
   float vmax = 0.f;
@@ -64,7 +64,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
   }
   if (out_bound) {
     vmax = wave_max(vmax);
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bound + blockIdx.y, absbits(vmax));
+    if ((threadIdx.x & 63) == 0) out_bound[((long)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)] = vmax;
   }
 }
 

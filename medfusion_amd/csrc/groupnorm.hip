@@ -54,10 +54,9 @@ struct GnSplit {
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual,
                                                         const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
-                                                        int HW, int C, int G, int act, const GnSplit sp) {
+                                                        int HW, int C, int G, int act) {
   const int C4 = C >> 2;
   const int cpg = C / G;
-  const long per4 = (long)HW * C4;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int c4 = (int)(i % C4);
@@ -87,16 +86,66 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
-    if (sp.outs) {
-      const float b = (stats || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
-      store_split4(sp.outs, i * 4, e[0], e[1], e[2], e[3], exp2i(-scale_exp_of(b)));
-      if (i == (long)n * per4) sp.out_bound[n] = b;
-    }
   }
 }
 
-// per-sample max of |x| -> bound[n] (order-preserving unsigned keys; zero on entry).  grid (blocks, N)
-__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, unsigned* __restrict__ bound, long per_sample4) {
+// The same pass with the fp16-pair copy: 8 channels (one 32-byte pair group) per thread, the per-sample scale recomputed only when the
+// grid-stride loop crosses into another sample.  The arithmetic per element is the one above (same operations, same order).
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ residual,
+                                                              const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total8,
+                                                              int HW, int C, int G, int act, const GnSplit sp) {
+  const int C8 = C >> 3;
+  const int cpg = C / G;
+  const long per8 = (long)HW * C8;
+  const long stride = (long)gridDim.x * blockDim.x;
+  int cur_n = -1;
+  float sc = 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += stride) {
+    const int c8 = (int)(i % C8);
+    const long pix = i / C8;
+    const int n = (int)(pix / HW);
+    const int c = c8 * 8;
+    if (n != cur_n) {
+      const float b = (stats || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
+      sc = exp2i(-scale_exp_of(b));
+      cur_n = n;
+      if (i == (long)n * per8) sp.out_bound[n] = b;
+    }
+    const float4 va = *reinterpret_cast<const float4*>(x + i * 8), vb = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    float e[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float t = e[k];
+      if (stats) {
+        const int g = (c + k) / cpg;
+        const float mean = stats[((long)n * G + g) * 2], rstd = stats[((long)n * G + g) * 2 + 1];
+        t = (t - mean) * rstd;
+        if (gamma) t = t * gamma[c + k] + beta[c + k];
+      }
+      if (act == 1) t = swish_acc(t);
+      e[k] = t;
+    }
+    if (residual) {
+      const float4 ra = *reinterpret_cast<const float4*>(residual + i * 8), rb = *reinterpret_cast<const float4*>(residual + i * 8 + 4);
+      e[0] += ra.x; e[1] += ra.y; e[2] += ra.z; e[3] += ra.w; e[4] += rb.x; e[5] += rb.y; e[6] += rb.z; e[7] += rb.w;
+    }
+    if (emb) {
+      const float4 ma = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c), mb = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c + 4);
+      e[0] += ma.x; e[1] += ma.y; e[2] += ma.z; e[3] += ma.w; e[4] += mb.x; e[5] += mb.y; e[6] += mb.z; e[7] += mb.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 8) = make_float4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(e[4], e[5], e[6], e[7]);
+    sf_u32x4 hi, lo;
+    split8_f16(sf_f32x4{e[0], e[1], e[2], e[3]} * sc, sf_f32x4{e[4], e[5], e[6], e[7]} * sc, hi, lo);
+    sf_u32x4* o = reinterpret_cast<sf_u32x4*>(sp.outs) + i * 2;
+    o[0] = hi;
+    o[1] = lo;
+  }
+}
+
+// max of |x| over this block's share of sample n -> partial[n][blockIdx.x * 4 + wave].  grid (blocks, N)
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, float* __restrict__ partial, long per_sample4) {
   const int n = blockIdx.y;
   const float4* p = reinterpret_cast<const float4*>(x) + (long)n * per_sample4;
   float m = 0.f;
@@ -105,70 +154,16 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(bound + n, absbits(m));
+  if ((threadIdx.x & 63) == 0) partial[((long)n * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = m;
 }
 
-// Same pass with the statistics FINALIZE fused in: grid (blocks_per_sample, N); every block first turns the P partial
-// records of its sample into mean / rstd for all G groups (fp64, a few KB from L2), then streams its slice of the sample.
-__global__ __launch_bounds__(256) void gn_apply_partial_kernel(const float* __restrict__ x, const double* __restrict__ partial, int P, double count,
-                                                                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ residual, const float* __restrict__ emb, long emb_stride,
-                                                                float* __restrict__ out, int HW, int C, int G, int act) {
-  extern __shared__ __attribute__((aligned(16))) float st[];  // [G][2] mean, rstd, then scratch doubles
-  const int n = blockIdx.y;
-  {
-    // finalize with all 256 threads: thread = (phase, g); phases stride over the P records, then an LDS tree over phases
-    double* red = reinterpret_cast<double*>(st + 2 * G + (2 * G & 1));  // 8-byte aligned scratch [phases][G][2]
-    const int phases = G <= 256 ? 256 / G : 1;
-    const int g = threadIdx.x % G, ph = threadIdx.x / G;
-    if (ph < phases) {
-      double s = 0, q = 0;
-      for (int c = ph; c < P; c += phases) {
-        const double* pp = partial + (((long)n * P + c) * G + g) * 2;
-        s += pp[0]; q += pp[1];
-      }
-      red[(ph * G + g) * 2] = s;
-      red[(ph * G + g) * 2 + 1] = q;
-    }
-    __syncthreads();
-    for (int gg = threadIdx.x; gg < G; gg += blockDim.x) {
-      double s = 0, q = 0;
-      for (int k = 0; k < phases; ++k) { s += red[(k * G + gg) * 2]; q += red[(k * G + gg) * 2 + 1]; }
-      const double mean = s / count;
-      double var = q / count - mean * mean;
-      if (var < 0) var = 0;
-      st[2 * gg] = (float)mean;
-      st[2 * gg + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-  }
-  __syncthreads();
-  const int C4 = C >> 2, cpg = C / G;
-  const long per4 = (long)HW * C4;
-  const long base4 = (long)n * per4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per4; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    const int c = c4 * 4;
-    const long e = (base4 + i) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + e);
-    float t[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int g = (c + k) / cpg;
-      float u = (t[k] - st[2 * g]) * st[2 * g + 1];
-      if (gamma) u = u * gamma[c + k] + beta[c + k];
-      if (act == 1) u = swish_acc(u);
-      t[k] = u;
-    }
-    if (residual) {
-      const float4 r = *reinterpret_cast<const float4*>(residual + e);
-      t[0] += r.x; t[1] += r.y; t[2] += r.z; t[3] += r.w;
-    }
-    if (emb) {
-      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
-      t[0] += m.x; t[1] += m.y; t[2] += m.z; t[3] += m.w;
-    }
-    *reinterpret_cast<float4*>(out + e) = make_float4(t[0], t[1], t[2], t[3]);
-  }
+// bound[n] = max over the slots of sample n.  One wave per sample.
+__global__ __launch_bounds__(64) void bound_finalize_kernel(const float* __restrict__ partial, float* __restrict__ bound, int slots) {
+  const int n = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < slots; i += 64) m = fmaxf(m, partial[(long)n * slots + i]);
+  m = wave_max(m);
+  if (threadIdx.x == 0) bound[n] = m;
 }
 
 }  // namespace
@@ -192,7 +187,7 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
   MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats: C=%d too wide", C);
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G, 1, 0L,
-                     (const float*)nullptr, (float*)nullptr, GnFinal{});
+                     (const float*)nullptr, (float*)nullptr);
   int rc = check_launch("gn_stats_partial");
   if (rc) return rc;
   const int NG = N * G;
@@ -223,42 +218,51 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   const long total4 = (long)N * HW * (C / 4);
   const double nelem = (double)N * HW * C;
   ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
+  if (out_split) {
+    const long total8 = total4 / 2;
+    long blocks = (total8 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total8, HW,
+                       C, G > 0 ? G : 1, act, sp);
+    return check_launch("gn_apply_split");
+  }
   long blocks = (total4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
-                     G > 0 ? G : 1, act, sp);
+                     G > 0 ? G : 1, act);
   return check_launch("gn_apply");
 }
 
-int mf_maxabs_rows_f32(const float* x, float* bound, int N, int64_t per_row, void* stream) {
-  MF_REQUIRE(x && bound && N > 0 && per_row > 0 && per_row % 4 == 0 && N <= 65535, MF_EINVAL, "maxabs_rows: bad args (per_row %% 4 == 0)");
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * N * (double)per_row);
+int mf_maxabs_rows_slots(int64_t per_row) {
   const long p4 = per_row / 4;
   int blocks = (int)((p4 + 1023) / 1024);
   if (blocks > 64) blocks = 64;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(maxabs_kernel, dim3(blocks, N), dim3(256), 0, s, x, reinterpret_cast<unsigned*>(bound), p4);
-  return check_launch("maxabs_rows");
+  return blocks * 4;
+}
+
+int mf_maxabs_rows_f32(const float* x, float* partial, float* bound, int N, int64_t per_row, void* stream) {
+  MF_REQUIRE(x && partial && bound && N > 0 && per_row > 0 && per_row % 4 == 0 && N <= 65535, MF_EINVAL, "maxabs_rows: bad args (per_row %% 4 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * N * (double)per_row);
+  const int slots = mf_maxabs_rows_slots(per_row);
+  hipLaunchKernelGGL(maxabs_kernel, dim3(slots / 4, N), dim3(256), 0, s, x, partial, (long)(per_row / 4));
+  int rc = check_launch("maxabs_rows");
+  if (rc) return rc;
+  hipLaunchKernelGGL(bound_finalize_kernel, dim3(N), dim3(64), 0, s, partial, bound, slots);
+  return check_launch("bound_finalize");
+}
+
+int mf_bound_finalize_f32(const float* partial, float* bound, int N, int slots, void* stream) {
+  MF_REQUIRE(partial && bound && N > 0 && slots > 0, MF_EINVAL, "bound_finalize: bad args");
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 4.0 * N * slots);
+  hipLaunchKernelGGL(bound_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partial, bound, slots);
+  return check_launch("bound_finalize");
 }
 
 
 int mf_gn_partial_parts(int HW) { return HW > 0 ? stats_chunks(HW) : 0; }
-
-int mf_gn_stats_fused_f32(const float* x, double* partial, float* stats, int32_t* counter, int N, int HW, int C, int G, float eps, void* stream) {
-  MF_REQUIRE(x && partial && stats && counter && N > 0 && HW > 0 && C > 0 && G > 0, MF_EINVAL, "gn_stats_fused: bad args");
-  MF_REQUIRE(C % 4 == 0 && C % G == 0, MF_EUNSUPPORTED, "gn_stats_fused: C=%d G=%d unsupported (need C%%4==0, C%%G==0)", C, G);
-  const int slices = stats_slices(N, HW, C, G), chunks = stats_chunks(HW);
-  const size_t lds = stats_lds_bytes(C / slices);
-  MF_REQUIRE(lds <= 64 * 1024 && G <= kStatsThreads, MF_EUNSUPPORTED, "gn_stats_fused: C=%d / G=%d too wide", C, G);
-  hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
-  const GnFinal fin{stats, counter, chunks * slices, chunks, (double)HW * (C / G), eps};
-  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
-                     (float*)nullptr, fin);
-  return check_launch("gn_stats_fused");
-}
 
 int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream) {
   MF_REQUIRE(partial && stats && parts > 0 && N > 0 && HW > 0 && G > 0 && C % G == 0, MF_EINVAL, "gn_finalize: bad args");
@@ -278,28 +282,8 @@ int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int 
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(stats_chunks(HW), N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
-                     (float*)nullptr, GnFinal{});
+                     (float*)nullptr);
   return check_launch("gn_stats_partial");
-}
-
-int mf_gn_apply_partial_f32(const float* x, const double* partial, int parts, float eps, const float* gamma, const float* beta, const float* residual,
-                            const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream) {
-  MF_REQUIRE(x && out && partial && parts > 0 && N > 0 && HW > 0 && C > 0 && G > 0, MF_EINVAL, "gn_apply_partial: bad args");
-  MF_REQUIRE(C % 4 == 0 && C % G == 0, MF_EUNSUPPORTED, "gn_apply_partial: C=%d G=%d unsupported", C, G);
-  MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply_partial: gamma/beta must both be given or both NULL");
-  MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "gn_apply_partial: emb_stride must be a multiple of 4");
-  MF_REQUIRE(N <= 65535 && G <= 256, MF_EUNSUPPORTED, "gn_apply_partial: N or G too large");
-  hipStream_t s = (hipStream_t)stream;
-  const long per4 = (long)HW * (C / 4);
-  const double nelem = (double)N * HW * C;
-  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0)));
-  long bps = (per4 + 2047) / 2048;            // >= 8 float4 per thread: amortises the per-workgroup finalize
-  const long cap = (1024 + N - 1) / N;        // ~1024 workgroups in total
-  if (bps > cap) bps = cap;
-  if (bps < 1) bps = 1;
-  hipLaunchKernelGGL(gn_apply_partial_kernel, dim3((int)bps, N), dim3(256), (size_t)(2 * G + 2) * sizeof(float) + (size_t)(G <= 256 ? 256 / G : 1) * G * 2 * sizeof(double), s, x, partial, parts, (double)HW * (C / G), eps,
-                     gamma, beta, residual, emb, (long)emb_stride, out, HW, C, G, act);
-  return check_launch("gn_apply_partial");
 }
 
 }  // extern "C"

@@ -58,8 +58,9 @@ __device__ __forceinline__ void store_split4(void* ys, long e, float a, float b,
   o[2] = sf_u32x2{l0, l1};
 }
 
-// |x| as an order-preserving unsigned key (atomicMax on it = running max of non-negative floats)
-__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+// Measured bounds: thousands of waves updating the same few words with atomics serialise on one L2 channel (measured: 66 us for a 10 us
+// pass), so every writer stores the max of its own share into its own slot of partial[n][slots] (plain stores, no zero fill needed:
+// every slot of the launch is written) and a tiny pass reduces the slots to bound[n] (mf_bound_finalize_f32).
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

@@ -106,13 +106,16 @@ def drop_split(t: Optional[torch.Tensor]) -> None:
 
 
 def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
-    """x [N, ...] contiguous fp32 -> bound [N] = max |x[n]| (measured on the device, no host sync)"""
+    """x [N, ...] contiguous fp32 -> bound [N] = max |x[n]| (measured on the device: two small launches, no atomics, no host sync)"""
     _gpu(x)
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise RuntimeError("maxabs_rows: contiguous fp32")
     n = x.shape[0]
-    bound = torch.zeros((n,), dtype=torch.float32, device=x.device)
-    L.check(L.load().mf_maxabs_rows_f32(x.data_ptr(), bound.data_ptr(), n, x.numel() // n, stream()), "mf_maxabs_rows_f32")
+    lib = L.load()
+    per = x.numel() // n
+    partial = torch.empty((n, lib.mf_maxabs_rows_slots(per)), dtype=torch.float32, device=x.device)
+    bound = torch.empty((n,), dtype=torch.float32, device=x.device)
+    L.check(lib.mf_maxabs_rows_f32(x.data_ptr(), partial.data_ptr(), bound.data_ptr(), n, per, stream()), "mf_maxabs_rows_f32")
     return bound
 
 
@@ -180,15 +183,18 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
         out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
     else:
         drop_split(out)
-    yb = torch.zeros((d.N,), dtype=torch.float32, device=x1.device) if measure_out else None
+    slots = lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if measure_out and not gn_groups else 0
+    yb = torch.empty((d.N, slots), dtype=torch.float32, device=x1.device) if slots else None
     partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=x1.device) if gn_groups else None
     need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
     rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), wmax, _ptr(yb), _ptr(ws), need,
                              _ptr(partial), gn_groups, C.byref(d), stream())
     L.check(rc, "mf_conv2d_f16x2")
-    if measure_out:
-        out._mf_bound = yb
+    if slots:   # reduce the per-(tile, wave) maxima to the bound of each sample (without slots a consumer measures on demand)
+        bound = torch.empty((d.N,), dtype=torch.float32, device=x1.device)
+        L.check(lib.mf_bound_finalize_f32(yb.data_ptr(), bound.data_ptr(), d.N, slots, stream()), "mf_bound_finalize_f32")
+        out._mf_bound = bound
     return (out, partial) if gn_groups else out
 
 
@@ -232,79 +238,25 @@ def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
-_COUNTERS = {}
-
-
-def _gn_counter(device, n: int) -> torch.Tensor:
-    """Per-(device, stream) arrival counters of the fused GroupNorm finalize: zero-initialised ONCE, every launch leaves them zero."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _COUNTERS.get(key)
-    if buf is None or buf.numel() < n:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("medfusion_amd: counter allocation during graph capture; run one eager warm-up first")
-        buf = torch.zeros(max(n, 256), dtype=torch.int32, device=device)
-        _COUNTERS[key] = buf
-    return buf
-
-
 def conv_gn_parts(d: L.MfConvDesc, G: int) -> int:
     """How many per-sample partial GroupNorm records this convolution emits itself (0: it cannot)."""
     return L.load().mf_conv2d_gn_parts(C.byref(d), G)
 
 
 def conv2d_gn(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, G: int, parts: int,
-              x2: Optional[torch.Tensor] = None, eps: float = 1e-5, finalize: bool = True):
-    """Convolution + the statistics of the GroupNorm that follows (conv epilogue or split-K reducer).
-    finalize=True: the last-arriving producer workgroup also reduces them -> (y NHWC, stats [N,G,2], partial); else stats is None."""
+              x2: Optional[torch.Tensor] = None):
+    """Convolution + the partial statistics of the GroupNorm that follows (conv epilogue or split-K reducer) -> (y NHWC, partial)."""
     _gpu(x1, x2, w_packed, bias)
     lib = L.load()
     ho, wo = conv_out_hw(d)
     out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
     partial = torch.empty((d.N, parts, G, 2), dtype=torch.float64, device=x1.device)
-    stats = torch.empty((d.N, G, 2), dtype=torch.float32, device=x1.device) if finalize else None
-    counter = _gn_counter(x1.device, d.N) if finalize else None
     need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
-    rc = lib.mf_conv2d_gn_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(), _ptr(stats),
-                              _ptr(counter), G, eps, C.byref(d), stream())
+    rc = lib.mf_conv2d_gn_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(), G, C.byref(d),
+                              stream())
     L.check(rc, "mf_conv2d_gn_f32")
-    return out, stats, partial
-
-
-def conv_gn_apply_ok(d: L.MfConvDesc, G: int) -> bool:
-    return bool(L.load().mf_conv2d_gn_apply_ok(C.byref(d), G))
-
-
-def conv2d_gn_apply(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, G: int, parts: int, gamma, beta,
-                    x2: Optional[torch.Tensor] = None, eps: float = 1e-5, act: int = 1, residual: Optional[torch.Tensor] = None,
-                    emb: Optional[torch.Tensor] = None, emb_stride: int = 0) -> torch.Tensor:
-    """conv -> GroupNorm -> (Swish) -> + residual -> + emb as ONE launch pair (split-K conv + fused reducer/finalize/apply)."""
-    _gpu(x1, x2, w_packed, bias, gamma, beta, residual, emb)
-    lib = L.load()
-    ho, wo = conv_out_hw(d)
-    out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
-    partial = torch.empty((d.N, parts, G, 2), dtype=torch.float64, device=x1.device)
-    counters = _gn_counter(x1.device, 2 * 8 * d.N)
-    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
-    ws = Workspace.get(need, x1.device)
-    rc = lib.mf_conv2d_gn_apply_f32(x1.data_ptr(), _ptr(x2), w_packed.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(ws), need, partial.data_ptr(),
-                                    counters.data_ptr(), G, eps, _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, act, C.byref(d), stream())
-    L.check(rc, "mf_conv2d_gn_apply_f32")
-    return out
-
-
-def gn_stats_fused(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
-    """x NHWC -> stats [N,G,2] in ONE launch (partial sums + last-arriver finalize)."""
-    _gpu(x)
-    n, h, w, c = x.shape
-    lib = L.load()
-    parts = lib.mf_gn_partial_parts(h * w)
-    partial = torch.empty((n, parts, G, 2), dtype=torch.float64, device=x.device)
-    stats = torch.empty((n, G, 2), dtype=torch.float32, device=x.device)
-    counter = _gn_counter(x.device, n)
-    L.check(lib.mf_gn_stats_fused_f32(x.data_ptr(), partial.data_ptr(), stats.data_ptr(), counter.data_ptr(), n, h * w, c, G, eps, stream()),
-            "mf_gn_stats_fused_f32")
-    return stats
+    return out, partial
 
 
 def gn_stats_partial(x: torch.Tensor, G: int):
@@ -327,22 +279,6 @@ def gn_finalize(partial: torch.Tensor, parts: int, HW: int, C: int, G: int, eps:
     stats = torch.empty((n, G, 2), dtype=torch.float32, device=partial.device)
     L.check(L.load().mf_gn_finalize_f32(partial.data_ptr(), parts, stats.data_ptr(), n, HW, C, G, eps, stream()), "mf_gn_finalize_f32")
     return stats
-
-
-def gn_apply_partial(x: torch.Tensor, partial: torch.Tensor, parts: int, gamma, beta, G: int, eps: float = 1e-5, act: int = 1,
-                     residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """finalise mean/rstd from the partial sums and apply norm + affine + act + residual + emb in one pass"""
-    _gpu(x, gamma, beta, residual, emb)
-    n, h, w, c = x.shape
-    if out is None:
-        out = torch.empty_like(x)
-    else:
-        drop_split(out)
-    rc = L.load().mf_gn_apply_partial_f32(x.data_ptr(), partial.data_ptr(), parts, eps, _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride,
-                                          out.data_ptr(), n, h * w, c, G, act, stream())
-    L.check(rc, "mf_gn_apply_partial_f32")
-    return out
 
 
 def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:

@@ -19,6 +19,7 @@ ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--splitk", type=int, default=0)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--precision", type=int, default=0)
+ap.add_argument("--zeros", action="store_true", help="all-zero operands: the DVFS give-back of the same instruction stream (power-bound or not?)")
 a = ap.parse_args()
 n, h, w, c1, c2, co, k, st, ups = (int(v) for v in a.shape.split(","))
 dev = torch.device("cuda:0")
@@ -27,6 +28,10 @@ x1 = torch.randn((n, h, w, c1), generator=g).to(dev)
 x2 = torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None
 wt = (torch.randn((4, co, 2, 2, c1 + c2) if ups == 2 else (co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
 b = torch.randn((co,), generator=g).to(dev)
+if a.zeros:
+    x1.zero_(); wt.zero_()
+    if x2 is not None:
+        x2.zero_()
 d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, ups, tile_hint=a.tile, splitk_hint=a.splitk, precision=a.precision)
 if a.precision == 3:
     wt = K.split_conv_weight(wt)

@@ -127,10 +127,10 @@ def main():
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37) if args.precision == 5 else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
+            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54) if args.precision == 5 else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
-                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 43: 128, 46: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
-                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 43: 128, 46: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
+                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 51: 128, 52: 128, 53: 128, 54: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
+                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 51: 128, 52: 128, 53: 64, 54: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
                 if ups == 2 and (h * w_) % bm:
                     continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):

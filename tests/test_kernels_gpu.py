@@ -244,9 +244,8 @@ def test_conv_subpixel_upsample(dev, case):
         assert relerr(K.nhwc_to_nchw(y), want) < 1e-5, (case, sk)
         parts = K.conv_gn_parts(d, 8)
         if parts:
-            y2, fstats, partial = K.conv2d_gn(xd, wsub, b.to(dev), d, 8, parts, x2=x2d)
+            y2, partial = K.conv2d_gn(xd, wsub, b.to(dev), d, 8, parts, x2=x2d)
             assert torch.equal(y2, y)
-            assert torch.equal(fstats, K.gn_finalize(partial, parts, 4 * h * w, co, 8))
             assert relerr(partial[..., 0].sum(1), want.double().reshape(n, 8, -1).sum(-1)) < 1e-4
             assert relerr(partial[..., 1].sum(1), (want.double() ** 2).reshape(n, 8, -1).sum(-1)) < 1e-5
     d = K.make_conv_desc(n, 5, 6, c1, c2, co, 3, 1, 1, 2)  # 30 source pixels: not a multiple of 64 -> refused, gather form is used
@@ -301,7 +300,7 @@ def test_groupnorm_swish_residual_emb(dev, case):
 
 @pytest.mark.parametrize("case", [(2, 16, 8, 64, 0, 128, 3, 32, 8), (16, 8, 8, 128, 128, 256, 3, 32, 0), (2, 32, 32, 64, 0, 64, 3, 8, 4), (1, 16, 16, 128, 0, 128, 1, 8, 8)])
 def test_conv_fused_groupnorm_statistics(dev, case):
-    """mf_conv2d_gn_f32 (stats from the conv epilogue or the split-K reducer) + mf_gn_apply_partial_f32 == conv -> GroupNorm -> Swish + residual."""
+    """mf_conv2d_gn_f32 (stats from the conv epilogue or the split-K reducer) + mf_gn_finalize_f32 + mf_gn_apply_f32 == conv -> GroupNorm -> Swish + residual."""
     from medfusion_amd import kernels as K
     n, h, w, c1, c2, co, k, g, tile = case
     x = _rand(f"fx{case}", (n, c1, h, w))
@@ -321,19 +320,15 @@ def test_conv_fused_groupnorm_statistics(dev, case):
         x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
         wp = K.pack_conv_weight(wt.to(dev))
         if parts > 0:
-            y, fstats, partial = K.conv2d_gn(xd, wp, b.to(dev), d, g, parts, x2=x2d)
+            y, partial = K.conv2d_gn(xd, wp, b.to(dev), d, g, parts, x2=x2d)
         else:
             y = K.conv2d(xd, wp, b.to(dev), d, x2=x2d)
             partial, parts = K.gn_stats_partial(y, g)
-            fstats = K.gn_stats_fused(y, g)
         ref_sum = yc.reshape(n, g, -1).sum(-1)
         assert relerr(partial[..., 0].sum(1), ref_sum) < 1e-5, (case, sk, parts)
         assert relerr(partial[..., 1].sum(1), (yc * yc).reshape(n, g, -1).sum(-1)) < 1e-5
-        out = K.gn_apply_partial(y, partial, parts, gamma.to(dev), beta.to(dev), g, 1e-5, 1, K.nchw_to_nhwc(res.to(dev)))
-        assert relerr(K.nhwc_to_nchw(out), want) < 1e-5, (case, sk, parts)
-        stats = K.gn_finalize(partial, parts, h * w, co, g)   # stand-alone finalize kernel ...
-        assert torch.equal(stats, fstats), (case, sk)          # ... == the last-arriver finalize fused into the producer (hot path)
-        assert torch.equal(K.gn_stats_fused(y, g), K.gn_stats(y, g))
+        stats = K.gn_finalize(partial, parts, h * w, co, g)
+        assert relerr(stats, K.gn_stats(y, g)) < 1e-6, (case, sk)
         out2 = K.gn_apply(y, stats, gamma.to(dev), beta.to(dev), g, 1, K.nchw_to_nhwc(res.to(dev)))
         assert relerr(K.nhwc_to_nchw(out2), want) < 1e-5, (case, sk, parts)
 
@@ -542,40 +537,6 @@ def test_image_egress_uint8(dev):
     assert torch.equal(got1, want1)
 
 
-@pytest.mark.parametrize("shape", [(16, 16, 16, 512, 512), (16, 8, 8, 1024, 1024), (4, 32, 32, 512, 256), (3, 16, 16, 256, 512), (16, 8, 8, 2048, 1024)])
-@pytest.mark.parametrize("prec", [1, 0])
-def test_conv_gn_apply_fused_epilogue(dev, shape, prec):
-    """mf_conv2d_gn_apply_f32 (split-K conv + ONE kernel for reduce / GroupNorm statistics / finalize / norm+Swish+residual+emb, values
-    kept in registers across a per-(sample, slice) meeting point) == the separate conv -> finalize -> apply launches, repeatedly (the
-    arrival counters are self-cleaning)."""
-    from medfusion_amd import kernels as K
-    n, h, w, ci, co = shape
-    G = 32
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn((n, h, w, ci), generator=g).to(dev)
-    wt = (torch.randn((co, ci, 3, 3), generator=g) / np.sqrt(9 * ci)).to(dev)
-    b = (torch.randn((co,), generator=g) * 0.1).to(dev)
-    gamma, beta = (1 + 0.1 * torch.randn((co,), generator=g)).to(dev), (0.1 * torch.randn((co,), generator=g)).to(dev)
-    res = torch.randn((n, h, w, co), generator=g).to(dev)
-    emb = torch.randn((n, co), generator=g).to(dev)
-    wp = K.pack_conv_weight(wt)
-    d = K.make_conv_desc(n, h, w, ci, 0, co, 3, 1, 1, 0, precision=3 if prec else 0)
-    wk = K.split_conv_weight(wp) if prec else wp
-    if not K.conv_gn_apply_ok(d, G):
-        pytest.skip("this plan does not split K")
-    parts = K.conv_gn_parts(d, G)
-    y, stats, partial = K.conv2d_gn(x, wk, b, d, G, parts, finalize=False)
-    stats = K.gn_finalize(partial, parts, h * w, co, G, 1e-5)
-    want = K.gn_apply(y, stats, gamma, beta, G, 1, res, emb, emb.stride(0))
-    for _ in range(3):
-        got = K.conv2d_gn_apply(x, wk, b, d, G, parts, gamma, beta, eps=1e-5, act=1, residual=res, emb=emb, emb_stride=emb.stride(0))
-        assert bool(torch.isfinite(got).all())
-        assert relerr(got, want) < 2e-6
-    got2 = K.conv2d_gn_apply(x, wk, b, d, G, parts, None, None, eps=1e-5, act=0)   # no affine, no act, no residual, no emb
-    want2 = K.gn_apply(y, stats, None, None, G, 0)
-    assert relerr(got2, want2) < 2e-6
-
-
 # ----------------------------------------------------------------------------- MF_CONV_FP32_F16X2 (fp16 pairs, LDS-DMA kernel)
 def _decode_pairs(xs, shape):
     """int32 fp16-pair tensor -> float64 hi + lo / 2048 (without the per-sample scale)"""
@@ -627,7 +588,8 @@ F16X2_CASES = [
     (2, 8, 8, 512, 512, 512, 3, 1, 0),   # out-block two-source, long K -> split-K
     (1, 7, 9, 96, 0, 192, 3, 1, 0),      # ragged M, Cout = 192
 ]
-F16X2_TILES = {31: (128, 256), 32: (256, 128), 33: (128, 128), 34: (128, 128), 35: (256, 64), 36: (128, 64), 37: (64, 256)}
+F16X2_TILES = {31: (128, 256), 32: (256, 128), 33: (128, 128), 34: (128, 128), 35: (256, 64), 36: (128, 64), 37: (64, 256),
+               51: (128, 128), 52: (128, 128), 53: (64, 128), 54: (128, 64)}   # 51-54: 4-wave workgroups, two per CU
 
 
 def _f16x2_tiles(case):

@@ -68,12 +68,11 @@ def test_precision_enum_matches_header():
 
 def test_planner_properties_over_many_descriptors():
     """randomised sweep of the planner through the C-ABI (host only): igemm eligibility follows the documented channel rule, the
-    split-K workspace is a whole number of output slabs, the sub-pixel form implies the implicit-GEMM path, and the fused-epilogue
-    predicate implies a split-K plan that can emit GroupNorm partials."""
+    split-K workspace is a whole number of output slabs, the sub-pixel form implies the implicit-GEMM path."""
     import random
     lib = L.load()
     rnd = random.Random(1234)
-    seen_split = seen_fused = 0
+    seen_split = 0
     for _ in range(400):
         n = rnd.choice([1, 2, 3, 8, 16])
         h = rnd.choice([4, 8, 9, 16, 32, 64])
@@ -109,7 +108,4 @@ def test_planner_properties_over_many_descriptors():
                 continue
             parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
             assert parts >= 0 and (ig or parts == 0)
-            if lib.mf_conv2d_gn_apply_ok(C.byref(d), G):
-                assert sk >= 2 and parts > 0
-                seen_fused += 1
-    assert seen_split > 20 and seen_fused > 10   # the sweep does exercise those branches
+    assert seen_split > 20   # the sweep does exercise that branch
