@@ -44,8 +44,6 @@ ARITH = {
     1: dict(kernel="conv_igemm_kernel<..., MODE 3>", pmc_match=("conv_igemm_kernel<", ", 3, "), terms=6, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
             text="fp32 operands split EXACTLY into 3 bf16 terms (24 bits), 6 product terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights "
                  "pre-split at load"),
-    2: dict(kernel="conv_igemm_kernel<..., MODE 2>", pmc_match=("conv_igemm_kernel<", ", 2, "), terms=6, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
-            text="as 1, per-chunk sums added by the VALU"),
     4: dict(kernel="conv_igemm_kernel<..., MODE 5>", pmc_match=("conv_igemm_kernel<", ", 5, "), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),

@@ -60,15 +60,13 @@ typedef struct MfConvDesc {
   int32_t precision;       /* arithmetic of the implicit-GEMM path (MF_CONV_*, below); the small/direct kernels are always plain fp32 */
 } MfConvDesc;
 /* MF_CONV_FP32: v_mfma_f32_32x32x2_f32, products and sums exactly those of an fp32 fma chain.
- * MF_CONV_FP32_SPLIT3: every fp32 operand is split EXACTLY into three bf16 terms (x = h + m + l, 8 significant bits each) and
+ * MF_CONV_FP32_SPLIT3_W3: every fp32 operand is split EXACTLY into three bf16 terms (x = h + m + l, 8 significant bits each) and
  *   a*b is accumulated in fp32 on the bf16 matrix cores as the six terms of order <= 2 (hh, hm, mh, mm, hl, lh); the dropped terms
- *   are < 2^-23 |a*b|.  16x the MFMA rate / 6 terms = 3/8 of the matrix time.  Measured against fp64 its error is at or below the
- *   fp32-MFMA kernel's on every shape of the path (the planner keeps one accumulation chain <= 96 chunks via split-K).
- * MF_CONV_FP32_SPLIT3_CHUNKSUM: the same, with a fresh MFMA accumulator per 32-deep K chunk added to the running sum by the VALU
- *   (round-to-nearest): 2-4x smaller error than MF_CONV_FP32, ~2 % slower than MF_CONV_FP32_SPLIT3.
- * MF_CONV_FP32_SPLIT3_W3: MF_CONV_FP32_SPLIT3 (bit-identical results) with `w_packed` pointing to the weights ALREADY split:
+ *   are < 2^-23 |a*b|.  16x the MFMA rate / 6 terms = 3/8 of the matrix time.  `w_packed` points to the weights ALREADY split:
  *   mf_split_conv_weight_bf16x3 turns either fp32 packing ([rows][K]) into [rows][K/8][3 pieces][8] bf16 (6 bytes per weight) once
- *   at load time; the kernel then moves them to LDS without any arithmetic.  Implicit-GEMM path only (mf_conv2d_is_igemm).
+ *   at load time; the activations are split in the kernel.  Measured against fp64 its error is at or below the fp32-MFMA kernel's on
+ *   every shape of the path (the planner keeps one accumulation chain <= 96 chunks via split-K).  Implicit-GEMM path only.
+ *   (Values 1 and 2 -- the same arithmetic with the weights split in the kernel, and its chunk-sum variant -- were retired in ABI 200.)
  * MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (round to nearest even), one MFMA term, fp32
  *   accumulate; `w_packed` points to weights converted by mf_convert_conv_weight_bf16 ([rows][K] bf16).  Error vs fp64 ~3e-3 per
  *   convolution (2^-9 per operand); never selected by default, has its own tolerance in the tests.  Implicit-GEMM path only.
@@ -79,8 +77,7 @@ typedef struct MfConvDesc {
  *   operands need no arithmetic in the kernel, both go HBM -> LDS by LDS-DMA.  Entry point mf_conv2d_f16x2 (operands produced by
  *   mf_split_f16x2 or by the split output of mf_gn_apply_split_f32); every operand tensor carries a per-sample power-of-two scale, so
  *   there is no range limit (mf_gn_apply_split_f32 below has the details). */
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3 = 1, MF_CONV_FP32_SPLIT3_CHUNKSUM = 2, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4,
-       MF_CONV_FP32_F16X2 = 5 };
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4, MF_CONV_FP32_F16X2 = 5 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],

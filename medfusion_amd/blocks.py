@@ -88,18 +88,18 @@ class _Packed:
 
 
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
-# Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*):
-#   1 (default) fp32 operands split exactly into three bf16 terms, the six leading product terms accumulated in fp32 on the bf16
-#     matrix cores -- error vs fp64 at or below the fp32-MFMA kernel's, 1.45x its speed;  0: v_mfma_f32_32x32x2_f32;  2: as 1 with
-#     per-chunk sums added by the VALU (the most accurate of the three);  4: opt-in REDUCED precision (operands rounded to bf16, one
-#     MFMA term; its own tolerance);  5: fp32 through PAIRS of fp16 (23-bit operands, three product terms, both operands moved to LDS
-#     by LDS-DMA; convolutions that are not on that kernel run as 1).  Read per call: set blocks.CONV_PRECISION or the env var.
-CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "1"))
+# Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
+#   5 (default) fp32 through PAIRS of fp16: 23-bit operands with a per-sample power-of-two scale, three product terms on the fp16 matrix
+#     cores, both operands moved to LDS by LDS-DMA -- error vs fp64 BELOW the fp32-MFMA kernel's (profiles/r02_split_accuracy.txt), the
+#     150-iteration trajectory at 1e-6 of the oracle, 1.5x the speed of 1.  Convolutions that are not on that kernel (edge layers) run as 1.
+#   1 fp32 operands split EXACTLY into three bf16 terms (24 bits; weights split once at load), six product terms on the bf16 matrix cores;
+#   0 v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain);
+#   4 opt-in REDUCED precision (operands rounded to bf16, one MFMA term; its own tolerance) -- never a default.
+CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "5"))
 
 
 def f16x2_mode() -> bool:
     return CONV_PRECISION == 5
-PRESPLIT_WEIGHTS = True  # precision 1 on the implicit-GEMM path: hand the kernel weights already split at load time (bit-identical, no VALU for B)
 
 
 class Conv(nn.Module):
@@ -151,13 +151,15 @@ class Conv(nn.Module):
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
         prec = CONV_PRECISION
+        if prec not in (0, 1, 4, 5):
+            raise RuntimeError(f"blocks.CONV_PRECISION = {prec}: 0 (fp32 MFMA), 1 (exact bf16 triplets), 4 (opt-in bf16) or 5 (fp16 pairs, default)")
         if prec == 5:
             if rows is None and in_layout == L.LAYOUT_NHWC and out_layout == L.LAYOUT_NHWC:
                 r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out)
                 if r is not None:
                     return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
-        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, prec, PRESPLIT_WEIGHTS)
+        key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, prec)
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
@@ -166,10 +168,10 @@ class Conv(nn.Module):
                 d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=prec)
                 if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
                     d = d2
-            if d.precision == 1 and PRESPLIT_WEIGHTS and rows is None and K.conv_is_igemm(d):
-                d.precision = 3  # MF_CONV_FP32_SPLIT3_W3
-            if d.precision == 4 and (rows is not None or not K.conv_is_igemm(d)):
-                d.precision = 0  # the small / edge convolutions are not on the implicit-GEMM kernel: plain fp32
+            if d.precision in (1, 4) and (rows is not None or not K.conv_is_igemm(d)):
+                d.precision = 0  # the small / edge convolutions are not on the implicit-GEMM kernel (and a row slice has no converted weights): plain fp32
+            elif d.precision == 1:
+                d.precision = 3  # MF_CONV_FP32_SPLIT3_W3: the weights are split into bf16 triplets once
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
             self._descs[key] = ent
         d, parts = ent

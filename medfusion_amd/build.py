@@ -15,7 +15,7 @@ CSRC = HERE / "csrc"
 OBJ = CSRC / "build"
 LIB = HERE / "libmedfusion_hip.so"
 SOURCES = ["api.hip", "conv.hip", "conv_f16x2.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
-HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_plan.h", "split_f16.h"]
+HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_plan.h", "split_f16.h", "conv_plan_table.inc"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall",
           "-Wno-unused-function"]
 LFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"]

@@ -9,14 +9,12 @@
 //    GroupNorm partial statistics); statistics from the epilogue when K is not split.
 //      MODE 0  MF_CONV_FP32: v_mfma_f32_32x32x2_f32.  LDS tiles [rows][32+4] floats, conflict-free ds_read_b128 (k permuted
 //              identically for A and B), register-prefetched double buffer, one barrier per chunk at the top.
-//      MODE 1  MF_CONV_FP32_SPLIT3: every fp32 operand split exactly into 3 bf16 terms, 6 product terms on
-//              v_mfma_f32_32x32x16_bf16, fp32 accumulate.  LDS rows [3 pieces][32 bf16] + pad.  The chunk's other work is cut into
-//              units pinned between the MFMAs; ONE barrier per chunk in the middle of the MFMA stream, next chunk's first-step
-//              fragments prefetched behind it.
-//      MODE 2  ..._CHUNKSUM: MODE 1 with per-chunk MFMA accumulators added by the VALU.
-//      MODE 3  ..._W3: MODE 1 with the weights already split at load time (the default of the product).
-//      MODE 4  MODE 3 with ONE LDS buffer, fragments held in registers, two 4-wave workgroups per CU (narrow VAE levels).
+//      MODE 3  MF_CONV_FP32_SPLIT3_W3: every fp32 operand split exactly into 3 bf16 terms (the weights once at load time, the
+//              activations by the staging threads), 6 product terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  LDS rows
+//              [3 pieces][32 bf16] + pad.  The chunk's other work is cut into units pinned between the MFMAs; ONE barrier per chunk in
+//              the middle of the MFMA stream, next chunk's first-step fragments prefetched behind it.
 //      MODE 5  MF_CONV_BF16: opt-in reduced precision (one bf16 term).
+//    (The default arithmetic of the product, MF_CONV_FP32_F16X2, has its own kernel and translation unit: conv_f16x2.{h,hip}.)
 //    FG: fast gather addressing (no fused nearest-x2 gather, < 2^24 source pixels).
 //  * conv_smallcin_kernel / conv_direct_kernel: the edge convolutions (Cin = 8|3, Cout = 8|3|16, NCHW edges): <0.2 % of the FLOPs.
 //  * DESIGN.md section 3 has the measurements and what was tried and rejected.
@@ -224,13 +222,14 @@ __global__ void convert_weight_bf16_kernel(const float* __restrict__ w, u32x2* _
 const TileCfg kCfgs[] = {
     {1, 128, 128, 2, 2, 32}, {2, 128, 64, 2, 2, 32}, {3, 64, 128, 2, 2, 32}, {4, 64, 64, 2, 2, 32}, {5, 128, 32, 4, 1, 32}, {6, 64, 32, 2, 1, 32},
     {7, 128, 128, 4, 2, 32}, {8, 128, 128, 2, 4, 32}, {9, 128, 256, 2, 4, 32}, {10, 256, 128, 4, 2, 32},
-    {11, 128, 128, 2, 2, 32}, {12, 64, 128, 2, 2, 32}, {13, 128, 64, 2, 2, 32},  // MF_CONV_FP32_SPLIT3_W3 only: single LDS buffer, two 4-wave workgroups per CU
     {23, 64, 128, 2, 2, 64}, {24, 64, 64, 2, 2, 64}, {27, 128, 128, 4, 2, 64}, {28, 128, 128, 2, 4, 64},  // BK = 64 (needs C1, C2 % 64 == 0)
 };
 
 int make_plan(const MfConvDesc* d, Plan* pl) {
   int rc = fill_geometry(d, pl);
   if (rc) return rc;
+  MF_REQUIRE(d->precision != 1 && d->precision != 2, MF_EUNSUPPORTED,
+             "conv: precision %d (in-kernel weight split / chunk-sum variant of the bf16-triplet arithmetic) was retired in ABI 200: use MF_CONV_FP32_SPLIT3_W3", d->precision);
   const int Cin = d->C1 + d->C2;
   pl->igemm = d->in_layout == MF_LAYOUT_NHWC && d->out_layout == MF_LAYOUT_NHWC && (d->C1 % 32 == 0) && (d->C2 % 32 == 0) &&
               (d->Cout % 32 == 0) && d->tile_hint >= 0;
@@ -249,7 +248,6 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv: bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     MF_REQUIRE(d->C1 % c->BK == 0 && d->C2 % c->BK == 0, MF_EINVAL, "conv: tile_hint %d needs channel counts divisible by %d", d->tile_hint, c->BK);
     MF_REQUIRE(d->precision == MF_CONV_FP32 || c->BK == 32, MF_EINVAL, "conv: tile_hint %d is not built for the split-bf16 mode", d->tile_hint);
-    MF_REQUIRE(d->precision == MF_CONV_FP32_SPLIT3_W3 || c->id < 11 || c->id > 13, MF_EINVAL, "conv: tile_hint %d needs MF_CONV_FP32_SPLIT3_W3", d->tile_hint);
     pl->cfg = *c;
   } else {
     // From scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.txt): the 8-wave 128x128 tile (2 waves per SIMD inside
@@ -276,12 +274,6 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
       if ((id == 9 || id == 10) && (long)cdiv(pl->M, id == 9 ? 128 : 256) * (d->Cout / (id == 9 ? 256 : 128)) * 16 < 224 &&
           !(d->upsample == 2 && hw_src % 128))
         id = 8;
-      // pre-split weights: the single-buffer two-workgroups-per-CU forms win where Cout is too narrow for the 256-wide tile
-      // (VAE decoder levels: 128 ch 0.204 vs 0.227 ms, 64 ch 0.269 vs 0.280 ms; profiles/r01_conv_sweep_split.txt)
-      if (d->precision == MF_CONV_FP32_SPLIT3_W3 && d->tile_hint == 0) {
-        if (id == 10 && d->Cout == 128 && !(d->upsample == 2 && hw_src % 128)) id = 11;
-        else if (id == 4 && pl->M >= 4096 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) id = 13;
-      }
     } else if (d->Cout % 128 == 0 && pl->M >= 128 && gflop >= 6.0 && !(d->upsample == 2 && hw_src % 128)) {
       id = 8;                              // 8 waves, 128x128: best for every large 3x3 shape
     } else if (d->Cout % 64 == 0) {
@@ -506,22 +498,9 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     p.y = reinterpret_cast<float*>(workspace);
   }
   {
-    const double terms = d->precision == MF_CONV_FP32 || d->precision == MF_CONV_BF16 ? 1.0 : 6.0;
+    const double terms = d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : 1.0;
     ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
-    if (d->precision == MF_CONV_FP32_SPLIT3_CHUNKSUM) {
-      switch (pl.cfg.id) {
-        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 2>(p, s); break;
-        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 2>(p, s); break;
-        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 2>(p, s); break;
-        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 2>(p, s); break;
-        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 2>(p, s); break;
-        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 2>(p, s); break;
-        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 2>(p, s); break;
-        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 2>(p, s); break;
-        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 2>(p, s); break;
-        default: set_error("conv: tile config %d is not built for the split-bf16 chunk-sum mode", pl.cfg.id); rc = MF_EINVAL;
-      }
-    } else if (d->precision == MF_CONV_BF16) {
+    if (d->precision == MF_CONV_BF16) {
       switch (pl.cfg.id) {
         case 1: rc = launch_igemm<128, 128, 2, 2, 32, 5>(p, s); break;
         case 2: rc = launch_igemm<128, 64, 2, 2, 32, 5>(p, s); break;
@@ -545,22 +524,6 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
         case 8: rc = launch_igemm<128, 128, 2, 4, 32, 3>(p, s); break;
         case 9: rc = launch_igemm<128, 256, 2, 4, 32, 3>(p, s); break;
         case 10: rc = launch_igemm<256, 128, 4, 2, 32, 3>(p, s); break;
-        case 11: rc = launch_igemm<128, 128, 2, 2, 32, 4>(p, s); break;
-        case 12: rc = launch_igemm<64, 128, 2, 2, 32, 4>(p, s); break;
-        case 13: rc = launch_igemm<128, 64, 2, 2, 32, 4>(p, s); break;
-        default: set_error("conv: tile config %d is not built for the split-bf16 mode", pl.cfg.id); rc = MF_EINVAL;
-      }
-    } else if (d->precision == MF_CONV_FP32_SPLIT3) {
-      switch (pl.cfg.id) {
-        case 1: rc = launch_igemm<128, 128, 2, 2, 32, 1>(p, s); break;
-        case 2: rc = launch_igemm<128, 64, 2, 2, 32, 1>(p, s); break;
-        case 3: rc = launch_igemm<64, 128, 2, 2, 32, 1>(p, s); break;
-        case 4: rc = launch_igemm<64, 64, 2, 2, 32, 1>(p, s); break;
-        case 6: rc = launch_igemm<64, 32, 2, 1, 32, 1>(p, s); break;
-        case 7: rc = launch_igemm<128, 128, 4, 2, 32, 1>(p, s); break;
-        case 8: rc = launch_igemm<128, 128, 2, 4, 32, 1>(p, s); break;
-        case 9: rc = launch_igemm<128, 256, 2, 4, 32, 1>(p, s); break;
-        case 10: rc = launch_igemm<256, 128, 4, 2, 32, 1>(p, s); break;
         default: set_error("conv: tile config %d is not built for the split-bf16 mode", pl.cfg.id); rc = MF_EINVAL;
       }
     } else

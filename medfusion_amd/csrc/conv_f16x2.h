@@ -7,7 +7,7 @@
 // out of 4).  A product is accumulated in fp32 on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32-MFMA rate) as three terms
 //   main  += wh * xh            cross += wh * xl' + wl' * xh            result = main + cross / 2048
 // the dropped term wl*xl is < 2^-22 |w x|.  Three matrix instructions per product instead of the six of the exact 3 x bf16 split
-// (MF_CONV_FP32_SPLIT3).  Range: every operand tensor carries a per-sample power-of-two scale (split_f16.h) -- the kernel multiplies
+// (MF_CONV_FP32_SPLIT3_W3).  Range: every operand tensor carries a per-sample power-of-two scale (split_f16.h) -- the kernel multiplies
 // its accumulators by the scales of the sample a pixel belongs to, and re-scales them once when the K loop moves from the first source
 // of a fused concat to the second (the two tensors have their own scales).
 //

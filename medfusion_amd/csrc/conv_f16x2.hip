@@ -20,6 +20,12 @@ const Tile2 kTiles2[] = {
 };
 inline int wgs_per_cu(const Tile2& t) { return (size_t)t.NST * (t.BM + t.BN) * 128 <= 80 * 1024 ? 2 : 1; }
 
+struct PlanEntry { int N, H, W, Cin, Cout, k, stride, ups, tile, sk; };
+const PlanEntry kPlanTable[] = {
+#include "conv_plan_table.inc"
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+};
+
 struct Plan2 {
   bool ok;
   Tile2 t;
@@ -44,41 +50,66 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
            d->upsample != 1 && d->tile_hint >= 0 && (double)d->N * d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * 4.0 < 4294967040.0 &&
            (double)d->Cout * pl->K * 4.0 * (d->upsample == 2 ? 4 : 1) < 4294967040.0;
   if (!pl->ok) return MF_OK;
-  const Tile2* c = nullptr;
+  // Choice of (tile, split-K): the exact entry of the sweep table for the shapes of the published models (conv_plan_table.inc, generated
+  // by scripts/conv_sweep.py --emit-table on MI355X), else a cost model fitted to the same sweeps (microseconds):
+  //   launch + prologue + epilogue  ~7
+  //   main loop                     ceil(workgroups / resident slots) * iterations * t_it(tile)
+  //   split-K reducer               4 + (sk + 1) * output bytes / 3.5 TB/s
+  const long out_bytes = (long)pl->M * d->Cout * 4;
+  auto valid = [&](const Tile2& k) { return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0); };
+  auto sk_ok = [&](int sk) { return sk >= 1 && sk <= pl->cgroups; };
+  auto chain_ok = [&](int sk) { return (long)cdiv(pl->cgroups, sk) * pl->taps <= 96; };  // the matrix core adds with truncation: one chain <= 96 chunks
+  const Tile2* c = nullptr;   // fixed by the hint or the table, else chosen by the model
+  int sk = 0;                 // 0: not decided yet
   if (d->tile_hint > 0) {
     for (const auto& k : kTiles2) if (k.id == d->tile_hint) c = &k;
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv(f16x2): bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
+    if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
   } else {
-    int id;
-    if (d->Cout % 256 == 0 && pl->M >= 128) id = 31;
-    else if (d->Cout % 128 == 0) id = pl->M >= 256 ? 32 : 33;
-    else id = pl->M >= 256 ? 35 : 36;
-    // exactly enough 128x128 tiles for one wave of workgroups and a short K: no split-K, no slabs
-    if ((id == 31 || id == 32) && pl->K <= 2304) {
-      const long t8 = (long)cdiv(pl->M, 128) * (d->Cout / 128);
-      if (t8 >= 224 && t8 <= 256) id = 33;
+    for (const auto& e : kPlanTable) {
+      if (e.N == d->N && e.H == d->Hin && e.W == d->Win && e.Cin == Cin && e.Cout == d->Cout && e.k == d->KH && e.stride == d->stride &&
+          e.ups == d->upsample) {
+        for (const auto& k : kTiles2) if (k.id == e.tile && valid(k)) c = &k;
+        if (c && sk_ok(e.sk)) sk = e.sk;
+        break;
+      }
     }
-    if (d->upsample == 2) {  // a tile must lie inside one sub-pixel phase
-      if (id == 32 && hw_src % 256) id = 33;
-      if (id == 35 && hw_src % 256) id = 36;
-      if (hw_src % 128 && d->Cout % 256 == 0) id = 37;
-    }
-    for (const auto& k : kTiles2) if (k.id == id) c = &k;
   }
-  if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
+  if (d->splitk_hint > 0) sk = d->splitk_hint;
+  if (c == nullptr || sk == 0) {
+    double best = 1e30;
+    const Tile2* bc = nullptr;
+    int bsk = 1;
+    for (const auto& k : kTiles2) {
+      if (c != nullptr && k.id != c->id) continue;   // tile already fixed
+      if (c == nullptr && k.id == 52) continue;       // (A/B form of 51, never chosen automatically)
+      if (!valid(k)) continue;
+      const long tiles = (long)cdiv(pl->M, k.BM) * (d->Cout / k.BN);
+      const int percu = wgs_per_cu(k);
+      for (int s = 1; s <= 32; s *= 2) {
+        if (sk != 0 && s != sk) continue;               // split-K already fixed
+        if (!sk_ok(s)) break;
+        if (sk == 0 && !chain_ok(s) && sk_ok(s * 2) && s < 32) continue;
+        const long wgs = tiles * s;
+        const long waves = (wgs + 256L * percu - 1) / (256L * percu);
+        const double its = (double)cdiv(pl->cgroups, s) * pl->taps;
+        double t_it = 0.68 * k.BM * k.BN / (128.0 * 128.0);                 // 8-wave tiles, one workgroup per CU
+        if (k.BM * k.BN <= 128 * 64) t_it = (wgs > 256 ? 0.80 : 0.43);      // half-size tiles: two per CU when the grid is that large
+        else if (percu == 2) t_it = (wgs > 256 ? 1.40 : 0.75);              // 4-wave 128 x 128
+        double cost = 7.0 + waves * (its + 3.0) * t_it;
+        if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;
+        if (cost < best) { best = cost; bc = &k; bsk = s; }
+      }
+    }
+    if (bc == nullptr) {
+      if (c == nullptr) { pl->ok = false; return MF_OK; }
+      bc = c;
+      bsk = sk ? sk : 1;
+    }
+    c = bc;
+    sk = bsk;
+  }
   pl->t = *c;
-  const long tiles = (long)cdiv(pl->M, c->BM) * (d->Cout / c->BN);
-  int sk = 1;
-  if (d->splitk_hint > 0) {
-    sk = d->splitk_hint;
-  } else {
-    // top the grid up to one wave of workgroups (256 CUs x 1 or 2 per CU by LDS); a slice keeps >= 18 chunk iterations
-    const int min_cg = pl->taps >= 4 ? 2 : 8;
-    const long wave = 256L * wgs_per_cu(*c);
-    while (tiles * sk * 2 <= wave && pl->cgroups / (sk * 2) >= min_cg && sk < 16) sk *= 2;
-    // the matrix core adds its 16 products and the accumulator with truncation: keep one accumulation chain <= 96 chunks
-    while ((pl->cgroups / sk) * pl->taps > 96 && pl->cgroups / (sk * 2) >= 1 && sk < 32) sk *= 2;
-  }
   if (sk > pl->cgroups) sk = pl->cgroups;
   pl->cg_per_split = cdiv(pl->cgroups, sk);
   pl->splitk = cdiv(pl->cgroups, pl->cg_per_split);

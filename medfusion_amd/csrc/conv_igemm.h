@@ -12,14 +12,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Timing experiments only (scripts/ablate_split.sh builds side libraries with -DMF_ABLATE=bits; results are then WRONG by design):
-// 1 no split arithmetic, 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no second-step fragment reads, 32 no MFMAs,
-// 64 LDS stores of values that do not depend on the global loads (isolates the wait for the loads).
-#ifndef MF_ABLATE
-#define MF_ABLATE 0
-#endif
-constexpr int kAblate = MF_ABLATE;
-
 namespace {
 
 struct ConvP {
@@ -84,33 +76,24 @@ __device__ __forceinline__ void split_bf16x3(const f32x4 v, u32x2& h, u32x2& m, 
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
-__global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_kernel(const ConvP p) {
   constexpr int NT = WM * WN * 64;
   // row pitch in 32-bit words.  MODE 0: BK floats + 4 (conflict-free ds_read_b128 for BK = 32 and 64).
   // MODE 1: [3 pieces][32 bf16] = 48 words + 4: pitch/4 = 13 is odd, so the 16 rows of a quarter-wave b128 read hit distinct banks.
   constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);  // MODE 5: 32 bf16 = 16 words + 4 (pitch/4 = 5, odd)
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(MODE == 0 || BK == 32, "split mode: BK = 32");
-  // MODE 4 = MODE 3 with ONE LDS buffer and 4-wave workgroups, two of them per CU: the fragments of a chunk are pulled into
-  // registers (barrier | 24 ds_read_b128 | barrier), then the same buffer is refilled with the next chunk while the MFMAs run from
-  // registers.  The two waves of a SIMD then belong to DIFFERENT workgroups with their own barrier cadence, so one computes while the
-  // other sits in its barrier/fragment-read window (with two waves of ONE workgroup per SIMD both sit there at the same time: the
-  // matrix pipe was 59 % busy, profiles/r01_pmc_conv_split.csv).
-#ifndef MF_MIDBARRIER
-#define MF_MIDBARRIER 1
-#endif
   // MB: the double-buffered split modes run with ONE barrier per chunk in the MIDDLE of the MFMA stream: before it a wave stores its
   // share of chunk k+1 and reads its last fragments of chunk k, after it the first-step fragments of chunk k+1 are prefetched into
   // the registers the first half of the MFMAs has finished with -- the next chunk's MFMAs start without a barrier and without an
   // exposed LDS round trip (the barrier window cost ~15 points of matrix-pipe utilisation: profiles/r01_mimic_probe.txt).
-  constexpr bool MB = MF_MIDBARRIER && MODE >= 1 && MODE != 4 && (MODE == 5 ? 1 : 6) * (BM / (WM * 32)) * (BN / (WN * 32)) >= 4;  // >= 8 MFMAs per chunk
-  constexpr bool SB = MODE == 4;
-  constexpr int NBUF = SB ? 1 : 2;
+  constexpr bool MB = MODE >= 1 && (MODE == 5 ? 1 : 6) * (BM / (WM * 32)) * (BN / (WN * 32)) >= 4;  // >= 8 MFMAs per chunk
+  static_assert(MODE == 0 || MODE == 3 || MODE == 5, "built arithmetics: fp32 MFMA (0), exact bf16 triplets with pre-split weights (3), bf16 (5)");
+  constexpr int NBUF = 2;
   // MODE 5 = MF_CONV_BF16 (opt-in, REDUCED precision): operands rounded to bf16 (RNE), one MFMA term, fp32 accumulate; weights
   // arrive already converted (mf_convert_conv_weight_bf16).  Same kernel with NP = 1 piece instead of 3.
   constexpr int NP = MODE == 5 ? 1 : 3, NTERM = MODE == 5 ? 1 : 6;
-  constexpr bool WS = MODE == 3 || MODE == 4 || MODE == 5;     // MF_CONV_FP32_SPLIT3_W3: the weights arrive as bf16 triplets [row][K/8][3 pieces][8] (no split, no VALU for B)
-  constexpr bool FLUSH = MODE == 2;  // MF_CONV_FP32_SPLIT3_CHUNKSUM: per-chunk MFMA accumulators, added into the running fp32 sum by the VALU (RNE)
+  constexpr bool WS = MODE != 0;     // the weights arrive converted: bf16 triplets [row][K/8][3 pieces][8] (MODE 3) or bf16 (MODE 5); no VALU for B
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int TPR = BK / 4;   // staging: TPR threads (float4 each) cover one BK-float row
   constexpr int RPP = NT / TPR;
@@ -202,13 +185,9 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // (the A footprint of the 32 workgroups of an XCD, > 4 MB L2) lay between two uses of a line and every tap pass missed
   // (rocprofv3: 50 % L2 hit rate, 7.7x the compulsory bytes fetched).  The weights stay [Cout][tap][Cin]: a chunk is still 128
   // contiguous bytes per row.
-#ifndef MF_KORDER
-#define MF_KORDER 1
-#endif
-  constexpr bool kTapInner = MF_KORDER == 1;
   const int taps_ = p.KH * p.KW;
-  int cc = kTapInner ? kc_beg / taps_ : kc_beg % p.cchunks;
-  int tap = kTapInner ? kc_beg - cc * taps_ : kc_beg / p.cchunks;
+  int cc = kc_beg / taps_;
+  int tap = kc_beg - cc * taps_;
   int ky = tap / p.KW, kx = tap - ky * p.KW;
 
   // Two register sets: set 0 holds chunk 0 during the cold start only, set 1 is the steady-state prefetch register set
@@ -268,23 +247,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   }
 #define MF_ADVANCE()                            \
   {                                             \
-    if (kTapInner) {                            \
-      ++kx;                                     \
-      const int w1_ = (kx == p.KW) ? 1 : 0;     \
-      kx = w1_ ? 0 : kx;                        \
-      ky += w1_;                                \
-      const int w2_ = (ky == p.KH) ? 1 : 0;     \
-      ky = w2_ ? 0 : ky;                        \
-      cc += w2_;                                \
-    } else {                                    \
-      ++cc;                                     \
-      const int w1_ = (cc == p.cchunks) ? 1 : 0; \
-      cc = w1_ ? 0 : cc;                        \
-      kx += w1_;                                \
-      const int w2_ = (kx == p.KW) ? 1 : 0;     \
-      kx = w2_ ? 0 : kx;                        \
-      ky += w2_;                                \
-    }                                           \
+    ++kx;                                       \
+    const int w1_ = (kx == p.KW) ? 1 : 0;       \
+    kx = w1_ ? 0 : kx;                          \
+    ky += w1_;                                  \
+    const int w2_ = (ky == p.KH) ? 1 : 0;       \
+    ky = w2_ ? 0 : ky;                          \
+    cc += w2_;                                  \
   }
 #define MF_LDS_STORE(BUF, SET)                                                                               \
   {                                                                                                          \
@@ -338,7 +307,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   // stored in iteration k-1 and is visible after the barrier (each wave drains lgkmcnt before arriving).
 #define MF_COMPUTE(SET, KC, DO_STORE, DO_LOAD)                                                                                        \
   {                                                                                                                  \
-    if (!MB && !(kAblate & 8)) __syncthreads();                                                                      \
+    if (!MB) __syncthreads();                                                                                        \
     const float* Ab = Aw + buf * BM * LDK;                                                                           \
     const float* Bb = Bw + buf * BN * LDK;                                                                           \
     if constexpr (MODE == 0) {                                                                                       \
@@ -373,15 +342,15 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
       }                                                                                                              \
       const float* An_ = Aw + (buf ^ 1) * BM * LDK;                                                                  \
       const float* Bn_ = Bw + (buf ^ 1) * BN * LDK;                                                                  \
-      float* sa_ = As + (SB ? 0 : buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                   \
-      float* sb_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                   \
+      float* sa_ = As + (buf ^ 1) * BM * LDK + srow * LDK + (skoff >> 1);                                           \
+      float* sb_ = Bs + (buf ^ 1) * BN * LDK + srow * LDK + (skoff >> 1);                                           \
       unsigned h0_ = 0, m0_ = 0, l0_ = 0, h1_ = 0, m1_ = 0, l1_ = 0;                                                 \
       int coff_ = 0, Cs_ = 0, tapoff_ = 0, tsel_ = 31;                                                               \
       unsigned Cs4_ = 0, cb4_ = 0;                                                                                   \
       bool lv_ = false;                                                                                              \
       __amdgpu_buffer_rsrc_t rs_ = rsw;                                                                              \
-      float* sw_ = Bs + (SB ? 0 : buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                         \
-      constexpr int NM = 2 * NTERM * TM * TN, RU = SB ? 0 : TM + TN, UA = (SB || MB) ? 3 * PA : 3 * (PA - 1);        \
+      float* sw_ = Bs + (buf ^ 1) * BN * LDK + wrow * LDK + wo * 4;                                                 \
+      constexpr int NM = 2 * NTERM * TM * TN, RU = TM + TN, UA = MB ? 3 * PA : 3 * (PA - 1);                          \
       constexpr int UB = RU + UA + (WS ? PW : 3 * PB);  /* units before the mid barrier (all of them without one) */ \
       constexpr int UI = MB ? UB + 1 + RU : UB;                                                                      \
       constexpr int HS = NM / 2;                                                                                     \
@@ -397,34 +366,14 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
         Cs4_ = (unsigned)Cs_ * 4u; cb4_ = (unsigned)(first_ ? c0_ : c0_ - p.C1) * 4u;                                \
         rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
       }                                                                                                              \
-      if constexpr (SB) { /* all fragments of the chunk into registers, then the buffer is free for chunk k+1 */      \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
-            fra[1][i][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + c * 16 + 8)); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                               \
-          _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                              \
-            frb[1][j][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + c * 16 + 8)); \
-        __syncthreads();                                                                                             \
-      } else if constexpr (!MB) {                                                                                    \
+      if constexpr (!MB) {                                                                                           \
         MF_ITEM_A(0, 0, SET) MF_ITEM_A(0, 1, SET) MF_ITEM_A(0, 2, SET)  /* covers the latency of the fragment reads */ \
       }                                                                                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
-      f32x16 accc[TM][TN];                                                                                           \
       _Pragma("unroll") for (int n = 0; n < NM; ++n) {                                                               \
         constexpr int kCA[6] = {2, 0, 1, 1, 0, 0}, kCB[6] = {0, 2, 1, 0, 1, 0};  /* smallest terms first */         \
         const int j_ = n % TN, i_ = (n / TN) % TM, t_ = NTERM == 1 ? 5 : (n / (TN * TM)) % 6, s_ = n / (TN * TM * NTERM);                 \
-        if (kAblate & 32) {                                                                                          \
-        } else if (FLUSH) {                                                                                          \
-          if (s_ == 0 && t_ == 0) {                                                                                  \
-            f32x16 z_;                                                                                               \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.f;                                              \
-            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], z_, 0, 0, 0); \
-          } else {                                                                                                   \
-            accc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], accc[i_][j_], 0, 0, 0); \
-          }                                                                                                          \
-        } else {                                                                                                     \
-          acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
-        }                                                                                                            \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fra[s_][i_][kCA[t_]], frb[s_][j_][kCB[t_]], acc[i_][j_], 0, 0, 0); \
         { /* the units of slot n.  Without the mid barrier: UI units spread evenly over the NM slots.  With it: the UB units  \
              before the barrier over the first half, the barrier after MFMA NM/2 - 1 (the last one that reads the first-step   \
              fragments), the RU prefetch units over the second half.  (No inner loop over u: it stayed rolled for the 48-MFMA   \
@@ -450,13 +399,8 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
         }                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
       }                                                                                                              \
-      if (FLUSH) {                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                               \
-          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] += accc[i][j][r];                            \
-      }                                                                                                              \
     }                                                                                                                \
-    if (!SB) buf ^= 1;                                                                                               \
+    buf ^= 1;                                                                                                        \
   }
 // work unit U of a split-mode chunk (see MF_COMPUTE): [0, RU) second-step fragment reads of one 32-row sub-tile; then 3 units
 // per staging item (items 1..NI-1).
@@ -464,8 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   {                                                                                                                  \
     const int u = (U);                                                                                               \
     if (u < RU) {                                                                                                    \
-      if (kAblate & 16) {                                                                                            \
-      } else if (u < TM) {                                                                                           \
+      if (u < TM) {                                                                                                  \
         _Pragma("unroll") for (int c = 0; c < NP; ++c)                                                                \
           fra[1][u < TM ? u : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Ab + u * 32 * LDK + c * 16 + 8)); \
       } else {                                                                                                       \
@@ -473,7 +416,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
           frb[1][u >= TM && u < RU ? u - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bb + (u - TM) * 32 * LDK + c * 16 + 8)); \
       }                                                                                                              \
     } else if (MB && u == UB) {  /* every wave has stored its share of chunk k+1 and read the last fragments of chunk k */ \
-      if (!(kAblate & 8)) __syncthreads();                                                                           \
+      __syncthreads();                                                                                               \
     } else if (MB && u > UB) {   /* first-step fragments of chunk k+1, into the registers MFMA NM/2 - 1 read last */      \
       const int v_ = u - UB - 1;                                                                                     \
       if (v_ < TM) {                                                                                                 \
@@ -484,7 +427,7 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
           frb[0][v_ >= TM && v_ < RU ? v_ - TM : 0][c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(Bn_ + (v_ - TM) * 32 * LDK + c * 16)); \
       }                                                                                                              \
     } else if (u < RU + UA) {                                                                                        \
-      MF_ITEM_A(((SB || MB) ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                              \
+      MF_ITEM_A((MB ? 0 : 1) + (u - RU) / 3, (u - RU) % 3, SET)                                                      \
     } else if constexpr (WS) {                                                                                       \
       MF_ITEM_W(u - RU - UA, SET)                                                                                    \
     } else {                                                                                                         \
@@ -494,19 +437,16 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
 // staging items of the chunk being stored.  PART 0/1: split two floats each into bf16 triplets, PART 2: the three 8-byte LDS
 // writes, then the register is free: gather the same row of the chunk this register set holds next.
 #define MF_SPLIT_PARTS(V, PART, DST)                                                                                 \
-    const f32x4 v_ = (kAblate & 64) ? f32x4{(float)tid, 1.f, 2.f, (float)kc} : (V);                                  \
+    const f32x4 v_ = (V);                                                                                            \
     const float e0_ = v_[0], e1_ = v_[1], e2_ = v_[2], e3_ = v_[3];                                                  \
     if constexpr (NP == 1) {                                                                                         \
       if ((PART) == 0) h0_ = round_bf16x2(e0_, e1_);                                                                 \
       if ((PART) == 1) h1_ = round_bf16x2(e2_, e3_);                                                                 \
-    } else if (kAblate & 1) {                                                                                        \
-      if ((PART) == 0) { h0_ = __builtin_amdgcn_perm(__float_as_uint(e1_), __float_as_uint(e0_), 0x07060302u); m0_ = h0_; l0_ = h0_; } \
-      if ((PART) == 1) { h1_ = __builtin_amdgcn_perm(__float_as_uint(e3_), __float_as_uint(e2_), 0x07060302u); m1_ = h1_; l1_ = h1_; } \
     } else {                                                                                                         \
       if ((PART) == 0) split2_bf16x3(e0_, e1_, h0_, m0_, l0_);                                                       \
       if ((PART) == 1) split2_bf16x3(e2_, e3_, h1_, m1_, l1_);                                                       \
     }                                                                                                                \
-    if ((PART) == 2 && !(kAblate & 2)) {                                                                             \
+    if ((PART) == 2) {                                                                                               \
       float* d_ = (DST);                                                                                             \
       *reinterpret_cast<u32x2*>(d_) = u32x2{h0_, h1_};                                                               \
       if constexpr (NP == 3) {                                                                                       \
@@ -518,13 +458,13 @@ __global__ __launch_bounds__(WM* WN * 64, (MODE == 4 ? 2 : 1)) void conv_igemm_k
   {                                                                                                                  \
     const int qa_ = (Q) < PA ? (Q) : 0;                                                                              \
     MF_SPLIT_PARTS(ra##SET[qa_], PART, sa_ + qa_ * RPP * LDK)                                                        \
-    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_A(SET, qa_)                                                          \
+    if ((PART) == 2) MF_GLOAD_A(SET, qa_)                                                                            \
   }
 #define MF_ITEM_B(Q, PART, SET)                                                                                      \
   {                                                                                                                  \
     const int qb_ = (Q) < PB ? (Q) : 0;                                                                              \
     MF_SPLIT_PARTS(rb##SET[qb_], PART, sb_ + qb_ * RPP * LDK)                                                        \
-    if ((PART) == 2 && !(kAblate & 4)) MF_GLOAD_B1(SET, qb_)                                                         \
+    if ((PART) == 2) MF_GLOAD_B1(SET, qb_)                                                                           \
   }
 #define MF_ITEM_W(Q, SET)                                                                                            \
   {                                                                                                                  \

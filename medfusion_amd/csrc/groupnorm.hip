@@ -89,33 +89,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
-// The same pass with the fp16-pair copy: 8 channels (one 32-byte pair group) per thread, the per-sample scale recomputed only when the
-// grid-stride loop crosses into another sample.  The arithmetic per element is the one above (same operations, same order).
+// The same pass with the fp16-pair copy (4 channels = half a pair group per thread: two 8-byte stores; an 8-channel form measured 25 %
+// slower), the per-sample scale recomputed only when the grid-stride loop crosses into another sample.  The arithmetic per element is
+// the one above (same operations, same order).
 __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ residual,
-                                                              const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total8,
+                                                              const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
                                                               int HW, int C, int G, int act, const GnSplit sp) {
-  const int C8 = C >> 3;
+  const int C4 = C >> 2;
   const int cpg = C / G;
-  const long per8 = (long)HW * C8;
+  const long per4 = (long)HW * C4;
   const long stride = (long)gridDim.x * blockDim.x;
   int cur_n = -1;
   float sc = 1.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += stride) {
-    const int c8 = (int)(i % C8);
-    const long pix = i / C8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int c4 = (int)(i % C4);
+    const long pix = i / C4;
     const int n = (int)(pix / HW);
-    const int c = c8 * 8;
+    const int c = c4 * 4;
     if (n != cur_n) {
       const float b = (stats || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
       sc = exp2i(-scale_exp_of(b));
       cur_n = n;
-      if (i == (long)n * per8) sp.out_bound[n] = b;
+      if (i == (long)n * per4) sp.out_bound[n] = b;
     }
-    const float4 va = *reinterpret_cast<const float4*>(x + i * 8), vb = *reinterpret_cast<const float4*>(x + i * 8 + 4);
-    float e[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+    float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
       float t = e[k];
       if (stats) {
         const int g = (c + k) / cpg;
@@ -127,20 +128,15 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
       e[k] = t;
     }
     if (residual) {
-      const float4 ra = *reinterpret_cast<const float4*>(residual + i * 8), rb = *reinterpret_cast<const float4*>(residual + i * 8 + 4);
-      e[0] += ra.x; e[1] += ra.y; e[2] += ra.z; e[3] += ra.w; e[4] += rb.x; e[5] += rb.y; e[6] += rb.z; e[7] += rb.w;
+      const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w;
     }
     if (emb) {
-      const float4 ma = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c), mb = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c + 4);
-      e[0] += ma.x; e[1] += ma.y; e[2] += ma.z; e[3] += ma.w; e[4] += mb.x; e[5] += mb.y; e[6] += mb.z; e[7] += mb.w;
+      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
+      e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
-    *reinterpret_cast<float4*>(out + i * 8) = make_float4(e[0], e[1], e[2], e[3]);
-    *reinterpret_cast<float4*>(out + i * 8 + 4) = make_float4(e[4], e[5], e[6], e[7]);
-    sf_u32x4 hi, lo;
-    split8_f16(sf_f32x4{e[0], e[1], e[2], e[3]} * sc, sf_f32x4{e[4], e[5], e[6], e[7]} * sc, hi, lo);
-    sf_u32x4* o = reinterpret_cast<sf_u32x4*>(sp.outs) + i * 2;
-    o[0] = hi;
-    o[1] = lo;
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    store_split4(sp.outs, i * 4, e[0], e[1], e[2], e[3], sc);
   }
 }
 
@@ -219,11 +215,10 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   const double nelem = (double)N * HW * C;
   ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
   if (out_split) {
-    const long total8 = total4 / 2;
-    long blocks = (total8 + 255) / 256;
+    long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
-    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total8, HW,
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
                        C, G > 0 ? G : 1, act, sp);
     return check_launch("gn_apply_split");
   }

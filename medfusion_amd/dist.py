@@ -45,9 +45,13 @@ def gather_images(local: torch.Tensor, num_samples: int, rank: int, world: int) 
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0], *local.shape[1:]))], dim=0)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous())
-    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    pad = pad.contiguous()
+    host = dist.get_backend() == "gloo" and pad.is_cuda   # gloo (CPU tests, single-GPU boxes) gathers host tensors; nccl == RCCL moves device memory
+    src = pad.cpu() if host else pad
+    bufs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(bufs, src)
+    out = torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+    return out.to(local.device) if host else out
 
 
 def sample_sharded(pipeline, num_samples, img_size, condition=None, noise=None, gather=True, **kwargs) -> torch.Tensor:

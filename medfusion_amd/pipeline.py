@@ -153,8 +153,7 @@ class DiffusionPipeline(nn.Module):
             raise TypeError("forward() got an unexpected keyword argument 'eta'")
         guidance_scale = kwargs.pop("guidance_scale", 1.0)
         un_cond = kwargs.pop("un_cond", None)
-        if kwargs.pop("cold_diffusion", False):
-            raise NotImplementedError("cold_diffusion is off the sampling path")
+        cold_diffusion = bool(kwargs.pop("cold_diffusion", False))
         if kwargs:
             raise TypeError(f"forward() got an unexpected keyword argument '{next(iter(kwargs))}'")
         if self.estimator_objective not in ("x_T", "x_0"):
@@ -175,6 +174,26 @@ class DiffusionPipeline(nn.Module):
         rev = list(reversed(timesteps))
         objective = 0 if self.estimator_objective == "x_T" else 1
         x_t = x_t.contiguous().clone()
+        if cold_diffusion:
+            # diffusion_pipeline.py:294 forwards the flag to forward() on every iteration: off the hot loop, so composed from the
+            # single-step API (forward() takes no posterior draw in this mode; the DDIM update and its draw are those of :297-304)
+            if use_graph or trace is not None:
+                raise ValueError("cold_diffusion runs through the single-step API: no graph capture, no trace")
+            for i, t in enumerate(rev):
+                tt = torch.full((B,), float(t), dtype=torch.float32, device=dev)
+                x_prior, x_0, x_T, _ = self.forward(x_t, tt, condition, None, guidance_scale=guidance_scale, cold_diffusion=True, un_cond=un_cond)
+                if use_ddim and i < len(rev) - 1:
+                    r = recs[i]
+                    n_ddim = noise.draw(tuple(x_t.shape))
+                    a = torch.full((B,), r.ddim_sqrt_an, dtype=torch.float32, device=dev)
+                    c = torch.full((B,), r.ddim_c, dtype=torch.float32, device=dev)
+                    sg = torch.full((B,), r.ddim_sigma, dtype=torch.float32, device=dev)
+                    x_t = K.rows_axpby(K.rows_axpby(x_0, a, x_T, c), None, n_ddim, sg)   # x0 sqrt(a') + c x_T + sigma noise
+                else:
+                    x_t = x_prior
+            if decode and self.latent_embedder is not None:
+                x_t = self.latent_embedder.decode(x_t)
+            return x_t
         if use_graph:
             self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective)
         else:

@@ -99,14 +99,21 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
-    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 1: fp32 split into 3 bf16 terms, 2: + chunk sums, 3: 1 with pre-split weights, 5: fp16 pairs (LDS-DMA kernel)")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 3: fp32 split exactly into 3 bf16 terms (weights split at load), 4: bf16 (opt-in), 5: fp16 pairs (LDS-DMA kernel)")
     ap.add_argument("--tiles", default="", help="comma list of tile ids to sweep (default: all built for the precision)")
+    ap.add_argument("--latent", type=int, default=32, help="UNet input size (32: 256-px models, 64: 512-px)")
+    ap.add_argument("--emit-table", default="", help="append the best (tile, split-K) of every shape to this file as planner table entries (precision 5)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     tot_auto = tot_best = tot_fl = 0.0
     print(f"{'shape':24s} {'M':>7s} {'N':>5s} {'K':>6s} {'GF':>7s} | {'auto ms':>8s} {'TF':>6s} | best cfg (tile,splitk) ms TF | all")
-    for name, n, h, w_, c1, c2, co, k, st, ups, cnt in unet_shapes(args.batch) + vae_shapes(args.vae_batch):
+    table = []
+    shapes = unet_shapes(args.batch) + vae_shapes(args.vae_batch)
+    if args.latent != 32:   # same architecture on a larger latent: every spatial size scales
+        f = args.latent // 32
+        shapes = [(nm, n, h * f, w * f, c1, c2, co, k, st, ups, cnt) for nm, n, h, w, c1, c2, co, k, st, ups, cnt in shapes]
+    for name, n, h, w_, c1, c2, co, k, st, ups, cnt in shapes:
         if args.only and args.only not in name:
             continue
         pad = 1 if k == 3 else 0
@@ -142,15 +149,23 @@ def main():
                         continue
                     if args.precision == 5 and sk > (c1 + c2) // 32:
                         continue
+                    if args.precision == 5 and -(-((c1 + c2) // 32) // sk) * (4 if ups == 2 else k * k) > 96:
+                        continue   # one accumulation chain <= 96 chunks (profiles/r02_split_accuracy.txt)
                     d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))
             res.sort()
         best = res[0] if res else (t_auto, 0, 0)
+        if res and best[0] < 0.985 * t_auto:   # keep the planner's own choice unless the sweep beats it by more than the noise
+            table.append((n, h, w_, c1 + c2, co, k, st, ups, best[1], best[2]))
         tot_auto += t_auto * cnt
         tot_best += best[0] * cnt
         tot_fl += gf * cnt
         allres = " ".join(f"{t}/{s}:{ms:.3f}" for ms, t, s in res[:8])
         print(f"{name:24s} {M:7d} {co:5d} {Kk:6d} {gf:7.2f} | {t_auto:8.3f} {gf / t_auto:6.1f} | ({best[1]},{best[2]}) {best[0]:.3f} {gf / best[0]:6.1f} | {allres}", flush=True)
+    if args.emit_table and table:
+        with open(args.emit_table, "a") as f:
+            for e in table:
+                f.write("    {%s},\n" % ", ".join(str(v) for v in e))
     print(f"TOTAL weighted: auto {tot_auto:.2f} ms ({tot_fl / tot_auto:.1f} TF)  best {tot_best:.2f} ms ({tot_fl / tot_best:.1f} TF)  flops {tot_fl:.1f} GF")
 
 

@@ -37,7 +37,7 @@ def dev():
 
 @pytest.fixture(params=[5, 1, 0], ids=["f16x2", "split3", "fp32mfma"], autouse=True)
 def conv_precision(request):
-    """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3, MF_CONV_FP32), same tolerances"""
+    """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3_W3, MF_CONV_FP32), same tolerances"""
     from medfusion_amd import blocks as BLK
     old = BLK.CONV_PRECISION
     BLK.CONV_PRECISION = request.param

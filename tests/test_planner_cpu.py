@@ -20,7 +20,7 @@ def test_which_convs_run_on_the_implicit_gemm_kernel():
     assert lib.mf_conv2d_is_igemm(C.byref(_d(2, 8, 8, 48, 0, 64))) == 0                # Cin % 32 != 0
 
 
-@pytest.mark.parametrize("prec", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("prec", [0, 3, 4, 5])
 def test_split_k_workspace_and_gn_parts_are_consistent(prec):
     lib = L.load()
     for shape in [(16, 32, 32, 256, 0, 256), (16, 16, 16, 512, 0, 512), (16, 8, 8, 1024, 1024, 1024), (4, 64, 64, 256, 0, 256), (1, 256, 256, 64, 0, 64)]:
@@ -36,7 +36,7 @@ def test_split_k_workspace_and_gn_parts_are_consistent(prec):
         assert 0 < parts <= max(16, h * w // 64)       # every large conv of the path can emit GroupNorm partials
         if prec == 5:
             assert lib.mf_conv2d_f16x2_ok(C.byref(d)) == 1
-        if prec in (1, 2, 3, 5):                         # split modes: one accumulation chain <= 96 chunks of 32
+        if prec in (3, 5):                               # split modes: one accumulation chain <= 96 chunks of 32
             chunks = 9 * (shape[3] + shape[4]) // 32
             assert chunks / max(sk, 1) <= 96
 
@@ -53,17 +53,19 @@ def test_bad_descriptors_are_refused_without_a_gpu():
     assert lib.mf_conv2d_workspace_bytes(C.byref(_d(16, 32, 32, 256, 0, 256, prec=7))) == 0   # unknown precision -> plan fails
     assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, k=5))) == 0
     assert b"" != lib.mf_last_error()
-    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, prec=1, tile=24))) == 0  # BK = 64 tile is fp32-only
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, prec=3, tile=24))) == 0  # BK = 64 tile is fp32-only
+    assert lib.mf_conv2d_is_igemm(C.byref(_d(16, 32, 32, 256, 0, 256, prec=1))) == 0           # retired in ABI 200 (in-kernel weight split)
+    assert b"retired" in lib.mf_last_error()
 
 
 def test_precision_enum_matches_header():
     import re
     from pathlib import Path
     txt = (Path(__file__).resolve().parents[1] / "include" / "medfusion_hip.h").read_text()
-    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3 = (\d), MF_CONV_FP32_SPLIT3_CHUNKSUM = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d),\s+MF_CONV_FP32_F16X2 = (\d) \}", txt)
-    assert m and [int(v) for v in m.groups()] == [0, 1, 2, 3, 4, 5]
+    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d), MF_CONV_FP32_F16X2 = (\d) \}", txt)
+    assert m and [int(v) for v in m.groups()] == [0, 3, 4, 5]
     from medfusion_amd import blocks as BLK
-    assert BLK.CONV_PRECISION in (0, 1, 2, 5)  # the reduced-precision mode (4) is never a default
+    assert BLK.CONV_PRECISION in (0, 1, 5)  # the reduced-precision mode (4) is never a default
 
 
 def test_planner_properties_over_many_descriptors():
@@ -83,7 +85,7 @@ def test_planner_properties_over_many_descriptors():
         k = rnd.choice([1, 3])
         stride = rnd.choice([1, 1, 2])
         ups = rnd.choice([0, 0, 1, 2]) if (k == 3 and stride == 1) else 0
-        prec = rnd.choice([0, 1, 2, 3, 4])
+        prec = rnd.choice([0, 3, 4])
         d = _d(n, h, w, c1, c2, co, k=k, stride=stride, ups=ups, prec=prec)
         ig = lib.mf_conv2d_is_igemm(C.byref(d))
         rule = c1 % 32 == 0 and c2 % 32 == 0 and co % 32 == 0
