@@ -163,15 +163,14 @@ class Conv(nn.Module):
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
         if ent is None:
-            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout, precision=prec)
+            dp = 3 if prec == 1 else prec   # exact bf16 triplets = MF_CONV_FP32_SPLIT3_W3 (the weights are split once at load)
+            d = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, self.upsample, in_layout, out_layout, precision=dp)
             if self.upsample and SUBPIXEL_UPSAMPLE and rows is None:
-                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=prec)
+                d2 = K.make_conv_desc(n, h, w, c1, c2, cout, self.k, self.stride, self.pad, 2, in_layout, out_layout, precision=dp)
                 if K.subpixel_ok(d2):  # 4 phase-specific 2x2 convs on the low-res tensor: 4/9 of the MACs
                     d = d2
-            if d.precision in (1, 4) and (rows is not None or not K.conv_is_igemm(d)):
+            if d.precision in (3, 4) and (rows is not None or not K.conv_is_igemm(d)):
                 d.precision = 0  # the small / edge convolutions are not on the implicit-GEMM kernel (and a row slice has no converted weights): plain fp32
-            elif d.precision == 1:
-                d.precision = 3  # MF_CONV_FP32_SPLIT3_W3: the weights are split into bf16 triplets once
             ent = (d, K.conv_gn_parts(d, gn_groups) if gn_groups else 0)
             self._descs[key] = ent
         d, parts = ent

@@ -142,8 +142,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 
   // load iterator (runs NST chunks ahead of the compute)
   int l_cc = cg_beg, l_ky = 0, l_kx = 0, l_it = 0, l_st = 0;
-  unsigned pbase[GP];
-  unsigned l_cs4 = 0;
+  unsigned pbase[GP], l_off[GP];
+  unsigned l_cs4 = 0, l_so = 0;
+  int l_lds = 0;
   __amdgpu_buffer_rsrc_t l_rs = rsw;
 
 #define MFC2_CHUNK_SETUP()                                                                                              \
@@ -155,20 +156,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     l_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(first_ ? p.x1 : p.x2), 0, first_ ? p.bytes1 : p.bytes2, 0x00020000); \
     _Pragma("unroll") for (int i = 0; i < GP; ++i) pbase[i] = (unsigned)a_pix[i] * l_cs4 + cb4_;                        \
   }
-// DMA instruction U (0 .. NL-1) of the chunk the load iterator points at, into LDS stage l_st
+// The DMA of the chunk the load iterator points at, in two parts so that nothing but the issue itself sits behind the barrier:
+// PREP (in the first half of an iteration, under its MFMAs): gather offsets of the activation rows, scalar offset of the weight rows,
+// LDS base of the target stage; ISSUE U (0 .. NL-1, second half): one buffer_load ... lds each.
+#define MFC2_LOAD_PREP()                                                                                                \
+  {                                                                                                                     \
+    const unsigned ts_ = (unsigned)(l_ky * p.KW + l_kx);                                                                \
+    const unsigned tapb_ = (unsigned)(l_ky * p.Win + l_kx) * l_cs4;                                                     \
+    _Pragma("unroll") for (int i = 0; i < GP; ++i) l_off[i] = (pbase[i] + tapb_) | (unsigned)__builtin_amdgcn_sbfe(a_inv[i], ts_, 1u); \
+    l_so = (ts_ * (unsigned)p.Cin + (unsigned)l_cc * 32u) * 4u;                                                         \
+    l_lds = l_st * STAGE + wave * 1024;                                                                                 \
+  }
 #define MFC2_LOAD_UNIT(U)                                                                                               \
   {                                                                                                                     \
     constexpr int u_ = (U);                                                                                             \
     if constexpr (u_ < GP) {                                                                                            \
-      const unsigned tapb_ = (unsigned)(l_ky * p.Win + l_kx) * l_cs4;                                                   \
-      const unsigned off_ = (pbase[u_] + tapb_) | (unsigned)__builtin_amdgcn_sbfe(a_inv[u_], (unsigned)(l_ky * p.KW + l_kx), 1u); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + (wave + NW * u_) * 1024), \
-                                               16, off_, 0, 0, 0);                                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_lds + NW * u_ * 1024), 16, l_off[u_], 0, 0, 0); \
     } else {                                                                                                            \
       constexpr int q_ = u_ - GP;                                                                                       \
-      const unsigned so_ = (unsigned)((l_ky * p.KW + l_kx) * p.Cin + l_cc * 32) * 4u + (unsigned)q_ * (8u * NW) * kbytes;     \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_st * STAGE + BM * ROWB + (wave + NW * q_) * 1024), \
-                                               16, qv, so_, 0, 0);                                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_lds + BM * ROWB + NW * q_ * 1024), 16, qv, \
+                                               l_so + (unsigned)q_ * (8u * NW) * kbytes, 0, 0);                         \
     }                                                                                                                   \
   }
 #define MFC2_LOAD_ADVANCE()                  \
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   }
 #define MFC2_LOAD_ALL()                                            \
   {                                                                \
+    MFC2_LOAD_PREP()                                               \
     MFC2_LOAD_UNIT(0) MFC2_LOAD_UNIT(1)                            \
     if constexpr (NL > 2) MFC2_LOAD_UNIT(NL > 2 ? 2 : 0)           \
     if constexpr (NL > 3) MFC2_LOAD_UNIT(NL > 3 ? 3 : 0)           \
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source.  The exponents are
   // re-derived from the bound arrays where they are needed (the source switch, the epilogue): nothing is kept live through the loop.
   const bool first_src1 = cg_beg * 32 < p.C1, last_src2 = (cg_end - 1) * 32 >= p.C1;
-  const int it_sw = (first_src1 && last_src2) ? (p.C1 / 32 - cg_beg) * taps : -1;   // first iteration that reads the second source
+  const int it_sw = __builtin_amdgcn_readfirstlane((first_src1 && last_src2) ? (p.C1 / 32 - cg_beg) * taps : -1);   // first iteration that reads the second source
 #define MFC2_PIXEL_EXPS(I)                                                                                              \
     const int pm_ = min(m0 + wm * FM + (I) * 32 + (lane & 31), p.M - 1);                                                \
     const int pn_ = pm_ / p.HWout;                                                                                      \
@@ -278,14 +286,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 #define MFC2_SLOT_A(N_, SB)                                                                                             \
   {                                                                                                                     \
     MFC2_MFMA(0, N_)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);   /* the matrix instruction first: everything else of the slot issues under it */  \
     constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(1, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(1, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
+    if constexpr ((N_) == NM - 1) MFC2_LOAD_PREP()   /* (addresses of the DMA the second half issues) */                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   }
 #define MFC2_SLOT_B(N_, SB, DO_LOAD)                                                                                    \
   {                                                                                                                     \
     MFC2_MFMA(1, N_)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
     constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(0, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(0, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \

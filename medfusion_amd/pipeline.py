@@ -180,7 +180,7 @@ class DiffusionPipeline(nn.Module):
             if use_graph or trace is not None:
                 raise ValueError("cold_diffusion runs through the single-step API: no graph capture, no trace")
             for i, t in enumerate(rev):
-                tt = torch.full((B,), float(t), dtype=torch.float32, device=dev)
+                tt = torch.full((B,), int(t), dtype=torch.long, device=dev)
                 x_prior, x_0, x_T, _ = self.forward(x_t, tt, condition, None, guidance_scale=guidance_scale, cold_diffusion=True, un_cond=un_cond)
                 if use_ddim and i < len(rev) - 1:
                     r = recs[i]

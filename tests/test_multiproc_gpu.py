@@ -1,0 +1,99 @@
+"""The N > 1 path on real devices: one process per rank, REAL `DiffusionPipeline.sample(shard=...)` on the GPU, the
+gather through torch.distributed.
+
+* two ranks that SHARE the one GPU of a single-GPU box, gather over gloo (host tensors): everything of the multi-GPU path except the
+  RCCL transport -- runs everywhere;
+* two ranks on two GPUs over nccl (= RCCL on ROCm) when the box has them;
+* `bench.py --gpus N` launches its own ranks, and refuses loudly when fewer than N devices are visible.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+import medfusion_amd as M
+from medfusion_amd import dist as D
+from medfusion_amd import published as P
+from medfusion_amd.unet import UNet, TimeEmbbeding, LabelEmbedder
+from medfusion_amd.vae import VAE
+backend, ngpu = sys.argv[1], int(sys.argv[2])
+rank, local, world = D.init_from_env(backend)
+dev = torch.device("cuda", local % ngpu)
+torch.cuda.set_device(dev)
+ukw = dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[32, 32, 64, 64], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], time_embedder=TimeEmbbeding,
+           time_embedder_kwargs={{"emb_dim": 64}}, cond_embedder=LabelEmbedder, cond_embedder_kwargs={{"emb_dim": 64, "num_classes": 3}},
+           deep_supervision=False, use_res_block=True, use_attention="none")
+pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, UNet, None, P.published_scheduler_kwargs(), ukw, estimator_objective="x_T", clip_x0=False)
+pipe.latent_embedder = VAE(in_channels=3, out_channels=3, emb_channels=8, spatial_dims=2, hid_chs=[32, 32, 64, 64], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], deep_supervision=1)
+P.seeded_fill(pipe.noise_estimator, "mp.unet.")
+P.seeded_fill(pipe.latent_embedder, "mp.vae.")
+pipe.to(dev).eval()
+n = 5                                            # odd: the shards differ by one row
+cond = (torch.arange(n, device=dev) % 3)
+full = D.sample_sharded(pipe, n, (8, 8, 8), condition=cond, noise=M.PhiloxDeviceNoise(31), guidance_scale=4.0, un_cond=None, steps=3, use_ddim=True)
+assert full.shape == (n, 3, 64, 64) and full.device == dev
+if rank == 0:
+    alone = pipe.sample(n, (8, 8, 8), condition=cond, noise=M.PhiloxDeviceNoise(31), guidance_scale=4.0, un_cond=None, steps=3, use_ddim=True)
+    err = float((full - alone).abs().max() / alone.abs().max())
+    print("MULTIPROC_OK", world, backend, err, flush=True)
+    assert err < 1e-5, err                       # (another batch size => another conv tiling / split-K order: not bit-equal)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(backend, world, ngpu, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=str(ROOT)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), str(script), backend, str(ngpu)]
+    r = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MULTIPROC_OK" in r.stdout, r.stdout[-2000:]
+    return r.stdout
+
+
+def test_two_ranks_sharing_one_gpu_gather_over_gloo(tmp_path):
+    assert torch.cuda.is_available()
+    _launch("gloo", 2, 1, tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs for the RCCL transport")
+def test_two_ranks_two_gpus_rccl(tmp_path):
+    _launch("nccl", 2, 2, tmp_path)
+
+
+def test_bench_launches_its_own_ranks_or_refuses_loudly(tmp_path):
+    """`python bench.py --gpus N` (no launcher around it): N ranks under torch.distributed.run when N devices exist, else exit code 2
+    with a message -- never a silent 1-GPU run labelled otherwise."""
+    n_vis = torch.cuda.device_count()
+    want = n_vis + 1 if n_vis < 2 else 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(want), "--steps", "1", "--warmup", "0", "--ddim-steps", "2", "--no-cpu-baseline",
+                        "--no-alt-path", "--no-roofline"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    if n_vis >= 2:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32
+    else:
+        assert r.returncode == 2 and "visible" in r.stderr, (r.returncode, r.stderr[-500:])

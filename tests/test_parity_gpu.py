@@ -438,3 +438,19 @@ def test_bf16_opt_in_mode_has_its_own_tolerance(dev, published, conv_precision):
         assert e_unet < BF16_TOL and max(errs) < BF16_TOL and relerr(got_img, want_img) < BF16_TOL
     finally:
         BLK.CONV_PRECISION = conv_precision
+
+
+@torch.no_grad()
+def test_cold_diffusion_through_the_loop(dev):
+    """`denoise(..., cold_diffusion=True)` (the reference forwards the flag to forward() on every iteration, diffusion_pipeline.py:294):
+    no posterior draw, the DDIM update unchanged -- against the oracle on the tiny pipeline."""
+    pipe = build_product_pipe(R.tiny_unet_kwargs(3, "none"), R.tiny_vae_kwargs(), "pipe_tiny", dev)
+    ora = build_oracle_pipe(R.tiny_unet_kwargs(3, "none"), R.tiny_vae_kwargs(), "pipe_tiny")
+    cond = torch.tensor([2, 0])
+    for use_ddim in (True, False):
+        ora.set_noise_fn(S.PhiloxNoise(61))
+        want = ora.sample(2, (8, 8, 8), condition=cond, guidance_scale=2.0, steps=4, use_ddim=use_ddim, cold_diffusion=True)
+        src = oracle_noise(61)
+        got = pipe.sample(2, (8, 8, 8), condition=cond.to(dev), guidance_scale=2.0, steps=4, use_ddim=use_ddim, cold_diffusion=True, noise=src)
+        assert src.draw_index == ora.noise_fn.draw
+        assert relerr(got, want) < 1e-3
