@@ -62,6 +62,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     run([cc, *LFLAGS, *[str(OBJ / (Path(s).stem + ".o")) for s in SOURCES], "-o", str(LIB)])
+    import ctypes
+    ctypes.CDLL(str(LIB))   # every symbol must resolve (a kernel stub the host pass dropped shows up here, not on the GPU box)
     return LIB
 
 

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   {                                                                                                                     \
     constexpr int u_ = (U);                                                                                             \
     if constexpr (u_ < GP) {                                                                                            \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_lds + NW * u_ * 1024), 16, l_off[u_], 0, 0, 0); \
+      const unsigned off_ = l_off[u_];   /* (a subscript written straight into the builtin's argument list makes the HOST pass drop the kernel stub without a diagnostic: hipcc 7.2) */ \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(l_rs, (__attribute__((address_space(3))) void*)(smem + l_lds + NW * u_ * 1024), 16, off_, 0, 0, 0); \
     } else {                                                                                                            \
       constexpr int q_ = u_ - GP;                                                                                       \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem + l_lds + BM * ROWB + NW * q_ * 1024), 16, qv, \
