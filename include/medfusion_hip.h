@@ -140,18 +140,14 @@ int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, in
  * out may alias x. */
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                     const float* emb, int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream);
-/* The general form of the pass.
- * Statistics: `stats` (mean / rstd, from mf_gn_finalize_f32) OR `gn_partial` (the [N][parts][G][2] records of the producing convolution:
- *   every thread reduces the records of its own group in fp64, so no finalize launch is needed; C / G % 4 == 0) OR neither (no normalisation).
- * out_split: also the fp16-pair form of `out` (operand of a following MF_CONV_FP32_F16X2 convolution; C % 8 == 0).  A fp16-pair tensor
- *   carries a per-sample power-of-two scale derived from an UPPER BOUND of |value| over the sample (fp16 stops at 65504, an un-normalised
- *   residual stream does not): the pass derives the bound of its output from its inputs --
- *   bound[n] = (normalised ? bconst : x_bound[n]) + res_bound[n] + emb_bound[n],  bconst >= max|act(gn(x) gamma + beta)| =
+/* The same pass, also writing the fp16-pair form of `out` (operand of a following MF_CONV_FP32_F16X2 convolution; C % 8 == 0).
+ * A fp16-pair tensor carries a per-sample power-of-two scale derived from an UPPER BOUND of |value| over the sample (fp16 stops at
+ * 65504, an un-normalised residual stream does not): the pass derives the bound of its output from its inputs --
+ *   bound[n] = (stats ? bconst : x_bound[n]) + res_bound[n] + emb_bound[n],  bconst >= max|act(gn(x) gamma + beta)| =
  *   max|gamma| sqrt(group size) + max|beta| -- scales sample n by 2^-(floor(log2 bound[n]) - 14) and publishes bound[n] in out_bound. */
-int mf_gn_apply_split_f32(const float* x, const float* stats, const double* gn_partial, int parts, float eps, const float* gamma,
-                          const float* beta, const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split,
-                          const float* x_bound, const float* res_bound, const float* emb_bound, float bconst, float* out_bound, int N, int HW,
-                          int C, int G, int act, void* stream);
+int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
+                          const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound,
+                          const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
 /* bound[n] = max |x[n][:]| over per_row elements: the measured operand bound of tensors no producer bounded analytically (network
  * input convolutions, embedding rows).  Two launches, no atomics: every wave stores the max of its share into its own slot of
  * `partial` (N * mf_maxabs_rows_slots(per_row) floats of caller scratch), then one wave per row reduces the slots.

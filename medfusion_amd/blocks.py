@@ -87,7 +87,6 @@ class _Packed:
         return self._w3
 
 
-FINALIZE_IN_APPLY = bool(int(os.environ.get("MEDFUSION_FINALIZE_IN_APPLY", "1")))  # GroupNorm mean / rstd reduced inside the apply pass (A/B switch)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
 #   5 (default) fp32 through PAIRS of fp16: 23-bit operands with a per-sample power-of-two scale, three product terms on the fp16 matrix
@@ -137,7 +136,7 @@ class Conv(nn.Module):
         else:
             y = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out)
             partial, parts = K.gn_stats_partial(y, gn_groups)
-        return y, _stats_of(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)
+        return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)
 
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
                 gn_eps: float = 1e-5, measure_out: bool = False):
@@ -189,15 +188,7 @@ class Conv(nn.Module):
         else:
             y = K.conv2d(x1, wp, b, d, x2=x2, out=out)
             partial, parts = K.gn_stats_partial(y, gn_groups)
-        return y, _stats_of(partial, parts, ho * wo, cout, gn_groups, gn_eps)
-
-
-def _stats_of(partial, parts, hw, c, groups, eps):
-    """how the apply pass gets mean / rstd: straight from the partial records (it reduces them itself: no finalize launch) whenever a
-    thread's four channels share a group, else through the finalize kernel"""
-    if FINALIZE_IN_APPLY and (c // groups) % 4 == 0:
-        return ("partial", partial, parts, eps)
-    return K.gn_finalize(partial, parts, hw, c, groups, eps)
+        return y, K.gn_finalize(partial, parts, ho * wo, cout, gn_groups, gn_eps)
 
 
 class GroupNorm(nn.Module):

@@ -50,72 +50,27 @@ struct GnSplit {
   float* out_bound;         // [N] written by the pass
 };
 
-// statistics straight from the partial records of the producing convolution (no finalize launch): every thread reduces the `parts`
-// records of the group its four channels belong to -- once, the grid stride keeps a thread on the same channels -- in fp64
-struct GnPart {
-  const double* partial;    // [N][parts][G][2] = {sum, sumsq}, or null (then `stats` holds mean / rstd)
-  int parts;
-  double count;             // elements per group
-  float eps;
-};
-
 // out = act(gn(x)*gamma + beta) + residual + emb[n][c]
-// SPLIT: also the fp16-pair copy (4 channels = half a pair group per thread: two 8-byte stores; an 8-channel form measured 25 % slower),
-// the per-sample scale recomputed only when the grid-stride loop crosses into another sample.
-// FROMPART: mean / rstd from the partial records (C / G % 4 == 0: the four channels of a thread share a group).
-template <bool SPLIT, bool FROMPART>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ residual,
                                                         const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
-                                                        int HW, int C, int G, int act, const GnSplit sp, const GnPart pp) {
+                                                        int HW, int C, int G, int act) {
   const int C4 = C >> 2;
   const int cpg = C / G;
-  const long per4 = (long)HW * C4;
   const long stride = (long)gridDim.x * blockDim.x;
-  const bool normalise = FROMPART || stats != nullptr;
-  int cur_n = -1, cur_ng = -1;
-  float sc = 1.f, mean_c = 0.f, rstd_c = 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
     const int c4 = (int)(i % C4);
     const long pix = i / C4;
     const int n = (int)(pix / HW);
     const int c = c4 * 4;
-    if (SPLIT && n != cur_n) {
-      const float b = (normalise || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
-      sc = exp2i(-scale_exp_of(b));
-      cur_n = n;
-      if (i == (long)n * per4) sp.out_bound[n] = b;
-    }
-    if (FROMPART) {
-      const int g = c / cpg;
-      if (n * G + g != cur_ng) {
-        double s = 0, q = 0;
-        for (int k = 0; k < pp.parts; ++k) {
-          const double* r = pp.partial + (((long)n * pp.parts + k) * G + g) * 2;
-          s += r[0];
-          q += r[1];
-        }
-        const double mean = s / pp.count;
-        double var = q / pp.count - mean * mean;
-        if (var < 0) var = 0;
-        mean_c = (float)mean;
-        rstd_c = (float)(1.0 / sqrt(var + (double)pp.eps));
-        cur_ng = n * G + g;
-      }
-    }
     float4 v = *reinterpret_cast<const float4*>(x + i * 4);
     float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float t = e[k];
-      if (normalise) {
-        float mean, rstd;
-        if (FROMPART) {
-          mean = mean_c; rstd = rstd_c;
-        } else {
-          const int g = (c + k) / cpg;
-          mean = stats[((long)n * G + g) * 2]; rstd = stats[((long)n * G + g) * 2 + 1];
-        }
+      if (stats) {
+        const int g = (c + k) / cpg;
+        const float mean = stats[((long)n * G + g) * 2], rstd = stats[((long)n * G + g) * 2 + 1];
         t = (t - mean) * rstd;
         if (gamma) t = t * gamma[c + k] + beta[c + k];
       }
@@ -131,7 +86,57 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
     *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
-    if (SPLIT) store_split4(sp.outs, i * 4, e[0], e[1], e[2], e[3], sc);
+  }
+}
+
+// The same pass with the fp16-pair copy (4 channels = half a pair group per thread: two 8-byte stores; an 8-channel form measured 25 %
+// slower), the per-sample scale recomputed only when the grid-stride loop crosses into another sample.  The arithmetic per element is
+// the one above (same operations, same order).
+__global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ residual,
+                                                              const float* __restrict__ emb, long emb_stride, float* __restrict__ out, long total4,
+                                                              int HW, int C, int G, int act, const GnSplit sp) {
+  const int C4 = C >> 2;
+  const int cpg = C / G;
+  const long per4 = (long)HW * C4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  int cur_n = -1;
+  float sc = 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+    const int c4 = (int)(i % C4);
+    const long pix = i / C4;
+    const int n = (int)(pix / HW);
+    const int c = c4 * 4;
+    if (n != cur_n) {
+      const float b = (stats || !sp.x_bound ? sp.bconst : sp.x_bound[n]) + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
+      sc = exp2i(-scale_exp_of(b));
+      cur_n = n;
+      if (i == (long)n * per4) sp.out_bound[n] = b;
+    }
+    float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float t = e[k];
+      if (stats) {
+        const int g = (c + k) / cpg;
+        const float mean = stats[((long)n * G + g) * 2], rstd = stats[((long)n * G + g) * 2 + 1];
+        t = (t - mean) * rstd;
+        if (gamma) t = t * gamma[c + k] + beta[c + k];
+      }
+      if (act == 1) t = swish_acc(t);
+      e[k] = t;
+    }
+    if (residual) {
+      const float4 r = *reinterpret_cast<const float4*>(residual + i * 4);
+      e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w;
+    }
+    if (emb) {
+      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
+      e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    store_split4(sp.outs, i * 4, e[0], e[1], e[2], e[3], sc);
   }
 }
 
@@ -189,40 +194,38 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
 
 int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
                     int64_t emb_stride, float* out, int N, int HW, int C, int G, int act, void* stream) {
-  return mf_gn_apply_split_f32(x, stats, nullptr, 0, 0.f, gamma, beta, residual, emb, emb_stride, out, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, N,
-                               HW, C, G, act, stream);
+  return mf_gn_apply_split_f32(x, stats, gamma, beta, residual, emb, emb_stride, out, nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, N, HW, C, G, act,
+                               stream);
 }
 
-int mf_gn_apply_split_f32(const float* x, const float* stats, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
-                          const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound,
-                          const float* res_bound, const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act,
-                          void* stream) {
+int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual, const float* emb,
+                          int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound, const float* emb_bound,
+                          float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream) {
   MF_REQUIRE(x && out && N > 0 && HW > 0 && C > 0, MF_EINVAL, "gn_apply: bad args");
-  MF_REQUIRE(!(stats && gn_partial), MF_EINVAL, "gn_apply: statistics either finalised (stats) or as partial records (gn_partial), not both");
-  MF_REQUIRE(!gn_partial || (parts > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0), MF_EUNSUPPORTED,
-             "gn_apply: statistics from partial records need parts > 0 and a multiple of 4 channels per group (else: mf_gn_finalize_f32 + stats)");
   MF_REQUIRE(!out_split || (C % 8 == 0 && out_bound), MF_EUNSUPPORTED, "gn_apply: the fp16-pair output needs C %% 8 == 0 and out_bound");
-  MF_REQUIRE(!out_split || stats || gn_partial || x_bound, MF_EINVAL, "gn_apply: the fp16-pair output of an un-normalised pass needs x_bound");
+  MF_REQUIRE(!out_split || stats || x_bound, MF_EINVAL, "gn_apply: the fp16-pair output of an un-normalised pass needs x_bound");
   MF_REQUIRE(!out_split || !residual || res_bound, MF_EINVAL, "gn_apply: the fp16-pair output needs res_bound with a residual");
   MF_REQUIRE(!out_split || !emb || emb_bound, MF_EINVAL, "gn_apply: the fp16-pair output needs emb_bound with an embedding");
   MF_REQUIRE(C % 4 == 0, MF_EUNSUPPORTED, "gn_apply: C=%d must be a multiple of 4", C);
-  MF_REQUIRE(!(stats || gn_partial) || (G > 0 && C % G == 0), MF_EINVAL, "gn_apply: C=%d G=%d", C, G);
+  MF_REQUIRE(!stats || (G > 0 && C % G == 0), MF_EINVAL, "gn_apply: C=%d G=%d", C, G);
   MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply: gamma/beta must both be given or both NULL");
   MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "gn_apply: emb_stride must be a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const long total4 = (long)N * HW * (C / 4);
   const double nelem = (double)N * HW * C;
   ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
+  if (out_split) {
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
+                       C, G > 0 ? G : 1, act, sp);
+    return check_launch("gn_apply_split");
+  }
   long blocks = (total4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
-  const GnPart pp{gn_partial, parts, (double)HW * (G > 0 ? C / G : 1), eps};
-  const int Gk = G > 0 ? G : 1;
-#define MF_GN_APPLY(SP, FP) hipLaunchKernelGGL((gn_apply_kernel<SP, FP>), dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, \
-                                               (long)emb_stride, out, total4, HW, C, Gk, act, sp, pp)
-  if (out_split) { if (gn_partial) MF_GN_APPLY(true, true); else MF_GN_APPLY(true, false); }
-  else { if (gn_partial) MF_GN_APPLY(false, true); else MF_GN_APPLY(false, false); }
-#undef MF_GN_APPLY
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
+                     G > 0 ? G : 1, act);
   return check_launch("gn_apply");
 }
 
