@@ -133,7 +133,7 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
  * mf_conv2d_gn_f32 / mf_conv2d_f16x2), a tiny finalize kernel, then the apply pass. */
 int mf_gn_partial_parts(int HW);
 int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int C, int G, void* stream);
-/* partial sums -> stats[n][g] = {mean, rstd} (tiny kernel; measured cheaper than finalising inside every apply workgroup) */
+/* partial sums -> stats[n][g] = {mean, rstd} (tiny kernel; mf_gn_apply_from_partials_f32 below folds it into the apply pass) */
 int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, int HW, int C, int G, float eps, void* stream);
 /* out = act(gn(x) * gamma + beta) + residual + emb[n*emb_stride + c]; act: 0 none, 1 Swish x*sigmoid(x).
  * gamma/beta NULL => no affine; stats NULL => no normalisation; residual / emb NULL => skipped.
@@ -148,6 +148,13 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
 int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                           const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound,
                           const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
+/* mf_gn_finalize_f32 + mf_gn_apply_split_f32 in ONE launch: mean / rstd are reduced from the partial records of the producing convolution
+ * ([N][parts][G][2], mf_conv2d_gn_f32 / mf_conv2d_f16x2) by the first G threads of every workgroup while its first loads are in flight.
+ * out_split NULL => fp32 output only (then the bound arguments are ignored). */
+int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
+                                  const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split,
+                                  const float* res_bound, const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G,
+                                  int act, void* stream);
 /* bound[n] = max |x[n][:]| over per_row elements: the measured operand bound of tensors no producer bounded analytically (network
  * input convolutions, embedding rows).  Two launches, no atomics: every wave stores the max of its share into its own slot of
  * `partial` (N * mf_maxabs_rows_slots(per_row) floats of caller scratch), then one wave per row reduces the slots.

@@ -140,6 +140,71 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
   }
 }
 
+// The pass fed by the PARTIAL records of the producing convolution -- no finalize launch in front of it.  grid (blocks per sample, N): a
+// block stays inside one sample, issues its first loads, and while they are in flight its first G threads reduce the sample's records
+// (fp64, the finalize kernel's formula) into LDS; the loop keeps one iteration of loads ahead of the arithmetic.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restrict__ x, const double* __restrict__ partial, int parts, double count, float eps,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ residual, const float* __restrict__ emb, long emb_stride,
+                                                            float* __restrict__ out, int HW, int C, int G, int act, const GnSplit sp) {
+  __shared__ float sm[2 * 256];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int C4 = C >> 2, cpg = C / G;
+  const long per4 = (long)HW * C4, base = (long)n * per4, step = (long)gridDim.x * 256;
+  long j = (long)blockIdx.x * 256 + tid;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), r = v;
+  if (j < per4) {
+    v = *reinterpret_cast<const float4*>(x + (base + j) * 4);
+    if (residual) r = *reinterpret_cast<const float4*>(residual + (base + j) * 4);
+  }
+  if (tid < G) {
+    double s = 0, q = 0;
+    for (int k = 0; k < parts; ++k) {
+      const double* p = partial + (((long)n * parts + k) * G + tid) * 2;
+      s += p[0]; q += p[1];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    sm[2 * tid] = (float)mean;
+    sm[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  float sc = 1.f;
+  if (SPLIT) {
+    const float b = sp.bconst + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
+    sc = exp2i(-scale_exp_of(b));
+    if (blockIdx.x == 0 && tid == 0) sp.out_bound[n] = b;
+  }
+  __syncthreads();
+  while (j < per4) {
+    const long jn = j + step;
+    float4 vn = v, rn = r;
+    if (jn < per4) {
+      vn = *reinterpret_cast<const float4*>(x + (base + jn) * 4);
+      if (residual) rn = *reinterpret_cast<const float4*>(residual + (base + jn) * 4);
+    }
+    const int c = (int)(j % C4) * 4;
+    float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int g = (c + k) / cpg;
+      float t = (e[k] - sm[2 * g]) * sm[2 * g + 1];
+      if (gamma) t = t * gamma[c + k] + beta[c + k];
+      if (act == 1) t = swish_acc(t);
+      e[k] = t;
+    }
+    if (residual) { e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w; }
+    if (emb) {
+      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
+      e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
+    }
+    *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    if (SPLIT) store_split4(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);
+    v = vn; r = rn; j = jn;
+  }
+}
+
 // max of |x| over this block's share of sample n -> partial[n][blockIdx.x * 4 + wave].  grid (blocks, N)
 __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ x, float* __restrict__ partial, long per_sample4) {
   const int n = blockIdx.y;
@@ -227,6 +292,34 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
                      G > 0 ? G : 1, act);
   return check_launch("gn_apply");
+}
+
+int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
+                                  const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split, const float* res_bound,
+                                  const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream) {
+  MF_REQUIRE(x && out && gn_partial && parts > 0 && N > 0 && N <= 65535 && HW > 0 && C > 0, MF_EINVAL, "gn_apply_from_partials: bad args");
+  MF_REQUIRE(G > 0 && G <= 256 && C % G == 0 && C % 4 == 0, MF_EUNSUPPORTED, "gn_apply_from_partials: C=%d G=%d (C %% 4 == 0, C %% G == 0, G <= 256)", C, G);
+  MF_REQUIRE(!out_split || (C % 8 == 0 && out_bound), MF_EUNSUPPORTED, "gn_apply_from_partials: the fp16-pair output needs C %% 8 == 0 and out_bound");
+  MF_REQUIRE(!out_split || !residual || res_bound, MF_EINVAL, "gn_apply_from_partials: the fp16-pair output needs res_bound with a residual");
+  MF_REQUIRE(!out_split || !emb || emb_bound, MF_EINVAL, "gn_apply_from_partials: the fp16-pair output needs emb_bound with an embedding");
+  MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply_from_partials: gamma/beta must both be given or both NULL");
+  MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "gn_apply_from_partials: emb_stride must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const long per4 = (long)HW * (C / 4);
+  const double nelem = (double)N * HW * C;
+  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
+  long bps = (per4 + 255) / 256;
+  const long cap = (256 * 8 + N - 1) / N;   // ~8 blocks per CU over the whole launch
+  if (bps > cap) bps = cap;
+  const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound};
+  const double count = (double)HW * (C / G);
+  if (out_split)
+    hipLaunchKernelGGL(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
+                       (long)emb_stride, out, HW, C, G, act, sp);
+  else
+    hipLaunchKernelGGL(gn_apply_part_kernel<false>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
+                       (long)emb_stride, out, HW, C, G, act, sp);
+  return check_launch("gn_apply_from_partials");
 }
 
 int mf_maxabs_rows_slots(int64_t per_row) {

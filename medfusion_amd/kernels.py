@@ -293,18 +293,30 @@ def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
     return stats
 
 
-def gn_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
+class GnPartials:
+    """the partial GroupNorm sums a convolution left ([N, parts, G, 2] fp64) handed to gn_apply un-finalised: the apply pass reduces them itself"""
+    __slots__ = ("records", "parts", "eps")
+
+    def __init__(self, records, parts, eps):
+        self.records, self.parts, self.eps = records, parts, eps
+
+
+def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
              emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None, split: bool = False,
              bconst: float = 0.0) -> torch.Tensor:
-    """split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution), scaled per sample
+    """stats: [N, G, 2] mean / rstd (gn_stats / gn_finalize), a GnPartials (mf_gn_apply_from_partials_f32: no finalize launch) or None.
+    split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution), scaled per sample
     by the bound the pass derives: bconst (>= max |act(gn(x) gamma + beta)|, from the caller; the bound of x when nothing is normalised)
     + the bounds of the residual and of the embedding rows."""
+    part = stats if isinstance(stats, GnPartials) else None
+    if part is not None:
+        stats = None
     _gpu(x, stats, gamma, beta, residual, emb)
     n, h, w, c = x.shape
     split = split and c % 8 == 0
     xb = rb = eb = ob = outs = None
     if split:  # (before `out` may alias x or the residual: their bounds describe the values this pass READS)
-        xb = bound_of(x) if stats is None else None
+        xb = bound_of(x) if (stats is None and part is None) else None
         rb = bound_of(residual) if residual is not None else None
         if emb is not None:
             eb = getattr(emb, "_mf_bound", None)
@@ -317,9 +329,15 @@ def gn_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, G: int
     if split:
         outs = torch.empty(out.shape, dtype=torch.int32, device=x.device)
         ob = torch.empty((n,), dtype=torch.float32, device=x.device)
-    rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
-                                        _ptr(outs), _ptr(xb), _ptr(rb), _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act, stream())
-    L.check(rc, "mf_gn_apply_split_f32")
+    if part is not None:
+        rc = L.load().mf_gn_apply_from_partials_f32(x.data_ptr(), part.records.data_ptr(), part.parts, float(part.eps), _ptr(gamma), _ptr(beta),
+                                                    _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(), _ptr(outs), _ptr(rb), _ptr(eb), float(bconst),
+                                                    _ptr(ob), n, h * w, c, G, act, stream())
+        L.check(rc, "mf_gn_apply_from_partials_f32")
+    else:
+        rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
+                                            _ptr(outs), _ptr(xb), _ptr(rb), _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act, stream())
+        L.check(rc, "mf_gn_apply_split_f32")
     if split:
         out._mf_split, out._mf_bound = outs, ob
     return out

@@ -7,7 +7,7 @@ mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT -o $c --output-format csv -- \
-    python $R/bench.py --steps 1 --warmup 0 --ddim-steps 6 --no-cpu-baseline --no-alt-path --no-roofline > $R/$OUT/run_$c.log 2>&1
+    python $R/bench.py --steps 1 --warmup 0 --ddim-steps 30 --no-cpu-baseline --no-alt-path --no-roofline > $R/$OUT/run_$c.log 2>&1
 done
 python - "$R/$OUT" <<'PY'
 import collections, csv, json, sys
@@ -27,7 +27,7 @@ for k, v in tab.items():
     out.append({"kernel": k[:160], "launches": len(v["FETCH_SIZE"]), "fetch_KiB_avg_raw": round(f, 1), "write_KiB_avg_raw": round(w, 1),
                 "hbm_bytes_per_launch": int((2 * f + w) * 1024), "total_fetch_KiB_raw": round(sum(v["FETCH_SIZE"]), 1)})
 out.sort(key=lambda e: -e["total_fetch_KiB_raw"])
-json.dump({"command": "bench.py --steps 1 --warmup 0 --ddim-steps 6 (cfg2 shapes, B=16, default conv arithmetic)",
+json.dump({"command": "bench.py --steps 1 --warmup 0 --ddim-steps 30 (cfg2 shapes, B=16, default conv arithmetic)",
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction)",
            "kernels": out[:12]}, open(f"{d}/traffic.json", "w"), indent=1)
 for e in out[:8]:

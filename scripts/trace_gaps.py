@@ -5,11 +5,13 @@ durations, the span, the idle time between consecutive dispatches (overall and b
 per-kernel totals.  usage: trace_gaps.py <..._kernel_trace.csv> [out.txt]"""
 import collections
 import csv
+import re
 import sys
 
 
 def short(n):
-    n = n.split("(")[0]
+    n = n.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void ", "", n).split("(")[0]
     return n if len(n) < 90 else n[:87] + "..."
 
 

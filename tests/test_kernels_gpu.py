@@ -296,6 +296,13 @@ def test_conv_fused_groupnorm_statistics(dev, case):
         assert relerr(stats, K.gn_stats(y, g)) < 1e-6, (case, sk)
         out2 = K.gn_apply(y, stats, gamma.to(dev), beta.to(dev), g, 1, K.nchw_to_nhwc(res.to(dev)))
         assert relerr(K.nhwc_to_nchw(out2), want) < 1e-5, (case, sk, parts)
+        # the same pass reducing the partial records itself (mf_gn_apply_from_partials_f32: no finalize launch)
+        resd, records = K.nchw_to_nhwc(res.to(dev)), K.GnPartials(partial, parts, 1e-5)
+        out3 = K.gn_apply(y, records, gamma.to(dev), beta.to(dev), g, 1, resd)
+        assert relerr(out3, out2) < 2e-7, (case, sk, parts)
+        bc = float(gamma.abs().max() * np.sqrt(co // g * h * w) + beta.abs().max())
+        out4 = K.gn_apply(y, records, gamma.to(dev), beta.to(dev), g, 1, resd, split=True, bconst=bc)
+        assert torch.equal(out4, out3) and torch.equal(out4._mf_split, K.split_f16x2(out3, out4._mf_bound))
 
 
 def test_groupnorm_large_group_fp64_combine(dev):
