@@ -113,14 +113,19 @@ def cpu_baseline(classes):
 
 
 def pmc_traffic(match):
-    """HBM bytes per launch of the most frequent conv tile: PMC counters cannot be read live, so they come from the committed rocprofv3
-    passes over this same command (scripts/pmc_bench_traffic.sh -> profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950)."""
+    """HBM bytes per conv launch (launch-weighted average over the kernel's tile instantiations) and of its most frequent tile: PMC counters
+    cannot be read live, so they come from the committed rocprofv3 passes over this same command (scripts/pmc_bench_traffic.sh ->
+    profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950)."""
     try:
         pj = json.load(open(ROOT / "profiles" / "pmc_bench_traffic.json"))
         cand = [e for e in pj["kernels"] if all(m in e["kernel"] for m in match)]
         if cand:
             top = max(cand, key=lambda e: e.get("launches", 0))
-            return top["hbm_bytes_per_launch"], f"profiles/pmc_bench_traffic.json [{top['kernel'][:80]}]: " + pj["method"]
+            n = sum(e["launches"] for e in cand)
+            avg = sum(e["launches"] * e["hbm_bytes_per_launch"] for e in cand) / n
+            return int(avg), {"file": "profiles/pmc_bench_traffic.json", "command": pj.get("command"), "method": pj["method"], "launches_profiled": n,
+                              "most_frequent_tile": {"kernel": top["kernel"][:80], "launches": top["launches"],
+                                                     "hbm_bytes_per_launch": top["hbm_bytes_per_launch"]}}
     except (OSError, KeyError, ValueError):
         pass
     return None, None
@@ -213,7 +218,7 @@ def main():
             pipe.sample(B, wl["latent"], condition=None if cond is None else cond[:B], noise=M.PhiloxDeviceNoise(7), steps=wl["steps"],
                         use_ddim=wl["use_ddim"], **({} if cond is None else dict(guidance_scale=wl["guidance"], un_cond=None)))
         tab = p.table()
-        ms, n, fl, _, ex = tab["conv_igemm"]
+        ms, n, fl, alg_bytes, ex = tab["conv_igemm"]
         total_ms = sum(v[0] for v in tab.values())
         alg = fl / (ms * 1e-3) / 1e12     # algorithmic FLOPs of the reference convolutions / their launch time
         exe = ex / (ms * 1e-3) / 1e12     # FLOPs the matrix pipe executes: terms per product x the MACs actually done (sub-pixel up-convs: 4/9)
@@ -231,7 +236,9 @@ def main():
                 "frac_arithmetic_ceiling": round(alg / (ar["peak"] / ar["terms"]), 4),
                 "arithmetic_ceiling_tflops": round(ar["peak"] / ar["terms"], 1),
                 "executed_over_algorithmic": round(ex / fl, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes per launch of the most frequent conv tile", "traffic_source": traffic_src,
+                "traffic": traffic, "traffic_unit": "HBM bytes per conv launch, launch-weighted average over the tile instantiations (PMC)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": int(alg_bytes / n),   # operands read once + output written once (fp32 sizes), same average
                 "launches": int(n), "avg_launch_ms": round(ms / n, 5), "share_of_gpu_time": round(ms / total_ms, 4),
                 "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])},
                 "hbm_bound_passes": hbm}

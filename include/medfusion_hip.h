@@ -150,11 +150,12 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
                           const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
 /* mf_gn_finalize_f32 + mf_gn_apply_split_f32 in ONE launch: mean / rstd are reduced from the partial records of the producing convolution
  * ([N][parts][G][2], mf_conv2d_gn_f32 / mf_conv2d_f16x2) by the first G threads of every workgroup while its first loads are in flight.
- * out_split NULL => fp32 output only (then the bound arguments are ignored). */
+ * out_split NULL => fp32 output only (then the bound arguments are ignored).  The residual's bound is res_bound[N], or -- res_bound NULL --
+ * the [N][res_nslots] slot maxima a convolution wrote (y_bound of mf_conv2d_f16x2), reduced inside the pass: no mf_bound_finalize_f32 launch. */
 int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
                                   const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split,
-                                  const float* res_bound, const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G,
-                                  int act, void* stream);
+                                  const float* res_bound, const float* res_bound_slots, int res_nslots, const float* emb_bound, float bconst,
+                                  float* out_bound, int N, int HW, int C, int G, int act, void* stream);
 /* bound[n] = max |x[n][:]| over per_row elements: the measured operand bound of tensors no producer bounded analytically (network
  * input convolutions, embedding rows).  Two launches, no atomics: every wave stores the max of its share into its own slot of
  * `partial` (N * mf_maxabs_rows_slots(per_row) floats of caller scratch), then one wave per row reduces the slots.

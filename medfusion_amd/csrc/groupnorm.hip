@@ -48,6 +48,8 @@ struct GnSplit {
   const float* emb_bound;   // [N] bound of |emb[n][:]|, or null
   float bconst;
   float* out_bound;         // [N] written by the pass
+  const float* res_slots;   // (from-partials pass) the residual's bound still as the [N][res_nslots] slot maxima its convolution wrote, or null
+  int res_nslots;
 };
 
 // out = act(gn(x)*gamma + beta) + residual + emb[n][c]
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ residual, const float* __restrict__ emb, long emb_stride,
                                                             float* __restrict__ out, int HW, int C, int G, int act, const GnSplit sp) {
-  __shared__ float sm[2 * 256];
+  __shared__ float sm[2 * 256 + 4];
   const int n = blockIdx.y, tid = threadIdx.x;
   const int C4 = C >> 2, cpg = C / G;
   const long per4 = (long)HW * C4, base = (long)n * per4, step = (long)gridDim.x * 256;
@@ -170,13 +172,20 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
     sm[2 * tid] = (float)mean;
     sm[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
   }
+  if (SPLIT && sp.res_slots) {   // the residual's measured bound, straight from the slots its convolution wrote (no finalize launch)
+    float m = 0.f;
+    for (int i = tid; i < sp.res_nslots; i += 256) m = fmaxf(m, sp.res_slots[(long)n * sp.res_nslots + i]);
+    m = wave_max(m);
+    if ((tid & 63) == 0) sm[2 * 256 + (tid >> 6)] = m;
+  }
+  __syncthreads();
   float sc = 1.f;
   if (SPLIT) {
-    const float b = sp.bconst + (sp.res_bound ? sp.res_bound[n] : 0.f) + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
+    const float rb = sp.res_slots ? fmaxf(fmaxf(sm[512], sm[513]), fmaxf(sm[514], sm[515])) : (sp.res_bound ? sp.res_bound[n] : 0.f);
+    const float b = sp.bconst + rb + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
     sc = exp2i(-scale_exp_of(b));
     if (blockIdx.x == 0 && tid == 0) sp.out_bound[n] = b;
   }
-  __syncthreads();
   while (j < per4) {
     const long jn = j + step;
     float4 vn = v, rn = r;
@@ -282,7 +291,7 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   if (out_split) {
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound};
+    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound, nullptr, 0};
     hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
                        C, G > 0 ? G : 1, act, sp);
     return check_launch("gn_apply_split");
@@ -296,11 +305,13 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
 
 int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
                                   const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split, const float* res_bound,
-                                  const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream) {
+                                  const float* res_bound_slots, int res_nslots, const float* emb_bound, float bconst, float* out_bound, int N, int HW,
+                                  int C, int G, int act, void* stream) {
   MF_REQUIRE(x && out && gn_partial && parts > 0 && N > 0 && N <= 65535 && HW > 0 && C > 0, MF_EINVAL, "gn_apply_from_partials: bad args");
   MF_REQUIRE(G > 0 && G <= 256 && C % G == 0 && C % 4 == 0, MF_EUNSUPPORTED, "gn_apply_from_partials: C=%d G=%d (C %% 4 == 0, C %% G == 0, G <= 256)", C, G);
   MF_REQUIRE(!out_split || (C % 8 == 0 && out_bound), MF_EUNSUPPORTED, "gn_apply_from_partials: the fp16-pair output needs C %% 8 == 0 and out_bound");
-  MF_REQUIRE(!out_split || !residual || res_bound, MF_EINVAL, "gn_apply_from_partials: the fp16-pair output needs res_bound with a residual");
+  MF_REQUIRE(!out_split || !residual || res_bound || (res_bound_slots && res_nslots > 0), MF_EINVAL,
+             "gn_apply_from_partials: the fp16-pair output needs res_bound (or res_bound_slots) with a residual");
   MF_REQUIRE(!out_split || !emb || emb_bound, MF_EINVAL, "gn_apply_from_partials: the fp16-pair output needs emb_bound with an embedding");
   MF_REQUIRE((gamma == nullptr) == (beta == nullptr), MF_EINVAL, "gn_apply_from_partials: gamma/beta must both be given or both NULL");
   MF_REQUIRE(!emb || emb_stride % 4 == 0, MF_EUNSUPPORTED, "gn_apply_from_partials: emb_stride must be a multiple of 4");
@@ -311,7 +322,7 @@ int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int 
   long bps = (per4 + 255) / 256;
   const long cap = (256 * 8 + N - 1) / N;   // ~8 blocks per CU over the whole launch
   if (bps > cap) bps = cap;
-  const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound};
+  const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots};
   const double count = (double)HW * (C / G);
   if (out_split)
     hipLaunchKernelGGL(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,

@@ -103,6 +103,8 @@ def drop_split(t: Optional[torch.Tensor]) -> None:
             t._mf_split = None
         if getattr(t, "_mf_bound", None) is not None:
             t._mf_bound = None
+        if getattr(t, "_mf_slots", None) is not None:
+            t._mf_slots = None
 
 
 def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
@@ -122,7 +124,12 @@ def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
 def bound_of(x: torch.Tensor) -> torch.Tensor:
     b = getattr(x, "_mf_bound", None)
     if b is None:
-        b = maxabs_rows(x)
+        sl = getattr(x, "_mf_slots", None)
+        if sl is not None:   # per-(tile, wave) maxima the producing convolution left: one wave per sample reduces them
+            b = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+            L.check(L.load().mf_bound_finalize_f32(sl.data_ptr(), b.data_ptr(), sl.shape[0], sl.shape[1], stream()), "mf_bound_finalize_f32")
+        else:
+            b = maxabs_rows(x)
         x._mf_bound = b
     return b
 
@@ -191,10 +198,8 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), wmax, _ptr(yb), _ptr(ws), need,
                              _ptr(partial), gn_groups, C.byref(d), stream())
     L.check(rc, "mf_conv2d_f16x2")
-    if slots:   # reduce the per-(tile, wave) maxima to the bound of each sample (without slots a consumer measures on demand)
-        bound = torch.empty((d.N,), dtype=torch.float32, device=x1.device)
-        L.check(lib.mf_bound_finalize_f32(yb.data_ptr(), bound.data_ptr(), d.N, slots, stream()), "mf_bound_finalize_f32")
-        out._mf_bound = bound
+    if slots:   # per-(tile, wave) maxima: reduced to the bound of each sample by the first consumer that asks (bound_of), or inside the
+        out._mf_slots = yb   # GroupNorm-apply pass that takes this tensor as its residual (without slots a consumer measures on demand)
     return (out, partial) if gn_groups else out
 
 
@@ -314,10 +319,14 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
     _gpu(x, stats, gamma, beta, residual, emb)
     n, h, w, c = x.shape
     split = split and c % 8 == 0
-    xb = rb = eb = ob = outs = None
+    xb = rb = eb = ob = outs = rslots = None
     if split:  # (before `out` may alias x or the residual: their bounds describe the values this pass READS)
         xb = bound_of(x) if (stats is None and part is None) else None
-        rb = bound_of(residual) if residual is not None else None
+        if residual is not None:
+            if part is not None and getattr(residual, "_mf_bound", None) is None and getattr(residual, "_mf_slots", None) is not None:
+                rslots = residual._mf_slots
+            else:
+                rb = bound_of(residual)
         if emb is not None:
             eb = getattr(emb, "_mf_bound", None)
             if eb is None:
@@ -331,8 +340,9 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
         ob = torch.empty((n,), dtype=torch.float32, device=x.device)
     if part is not None:
         rc = L.load().mf_gn_apply_from_partials_f32(x.data_ptr(), part.records.data_ptr(), part.parts, float(part.eps), _ptr(gamma), _ptr(beta),
-                                                    _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(), _ptr(outs), _ptr(rb), _ptr(eb), float(bconst),
-                                                    _ptr(ob), n, h * w, c, G, act, stream())
+                                                    _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(), _ptr(outs), _ptr(rb), _ptr(rslots),
+                                                    0 if rslots is None else rslots.shape[1], _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act,
+                                                    stream())
         L.check(rc, "mf_gn_apply_from_partials_f32")
     else:
         rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),

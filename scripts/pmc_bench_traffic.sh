@@ -1,13 +1,13 @@
 #!/bin/bash
-# HBM traffic of the bench's kernels: rocprofv3 PMC passes over a SHORT run of the bench command (FETCH_SIZE and WRITE_SIZE in
+# HBM traffic of the bench's kernels: rocprofv3 PMC passes over ONE step of the bench command (FETCH_SIZE and WRITE_SIZE in
 # separate passes with --kernel-trace only, as MI355X_MICROARCH.md prescribes), summarised per kernel and per launch.
 # usage (GPU box): scripts/pmc_bench_traffic.sh gpurun_out/pmc_traffic   ->  <out>/traffic.json  (copy to profiles/pmc_bench_traffic.json)
 OUT=$1; R=$GRAFT_REPO_ROOT
 mkdir -p $R/$OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT -o $c --output-format csv -- \
-    python $R/bench.py --steps 1 --warmup 0 --ddim-steps 30 --no-cpu-baseline --no-alt-path --no-roofline > $R/$OUT/run_$c.log 2>&1
+  timeout 1200 rocprofv3 --pmc $c --kernel-trace -d $R/$OUT -o $c --output-format csv -- \
+    python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-alt-path --no-roofline > $R/$OUT/run_$c.log 2>&1
 done
 python - "$R/$OUT" <<'PY'
 import collections, csv, json, sys
@@ -27,9 +27,9 @@ for k, v in tab.items():
     out.append({"kernel": k[:160], "launches": len(v["FETCH_SIZE"]), "fetch_KiB_avg_raw": round(f, 1), "write_KiB_avg_raw": round(w, 1),
                 "hbm_bytes_per_launch": int((2 * f + w) * 1024), "total_fetch_KiB_raw": round(sum(v["FETCH_SIZE"]), 1)})
 out.sort(key=lambda e: -e["total_fetch_KiB_raw"])
-json.dump({"command": "bench.py --steps 1 --warmup 0 --ddim-steps 30 (cfg2 shapes, B=16, default conv arithmetic)",
+json.dump({"command": "bench.py --steps 1 --warmup 0 (cfg2: B=16, 150 iterations + decode, default conv arithmetic)",
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction)",
-           "kernels": out[:12]}, open(f"{d}/traffic.json", "w"), indent=1)
+           "kernels": out[:24]}, open(f"{d}/traffic.json", "w"), indent=1)
 for e in out[:8]:
     print(e["launches"], e["hbm_bytes_per_launch"] / 1e6, "MB/launch", e["kernel"][:90])
 PY

@@ -641,3 +641,30 @@ def test_gn_apply_split_mirror(dev):
     assert torch.equal(y._mf_split, K.split_f16x2(y, y._mf_bound))
     K.add(y, res, out=y)                      # writing into a tensor drops its (now stale) mirrors
     assert getattr(y, "_mf_split", None) is None and getattr(y, "_mf_bound", None) is None
+
+
+def test_gn_apply_from_partials_with_residual_bound_slots(dev):
+    """the block epilogue of a channel-changing ResBlock in the default arithmetic: 3x3 conv leaving GroupNorm partial records, 1x1 conv_res
+    leaving per-(tile, wave) maxima; mf_gn_apply_from_partials_f32 reduces both itself and must equal the path through the finalize launches"""
+    from medfusion_amd import kernels as K
+    n, h, w, ci, co, g = 3, 16, 16, 64, 128, 8
+    x = K.nchw_to_nhwc(_rand("rs_x", (n, ci, h, w)).to(dev) * torch.tensor([1.0, 300.0, 1e-3], device=dev).view(n, 1, 1, 1))
+    w3, w1 = _rand("rs_w3", (co, ci, 3, 3), 0.05).to(dev), _rand("rs_w1", (co, ci, 1, 1), 0.2).to(dev)
+    b3, b1 = _rand("rs_b3", (co,), 0.1).to(dev), _rand("rs_b1", (co,), 0.1).to(dev)
+    gamma, beta = (1 + 0.2 * _rand("rs_g", (co,))).to(dev), _rand("rs_z", (co,), 0.1).to(dev)
+    d3 = K.make_conv_desc(n, h, w, ci, 0, co, 3, 1, 1, 0, precision=5)
+    d1 = K.make_conv_desc(n, h, w, ci, 0, co, 1, 1, 0, 0, precision=5)
+    parts = K.conv_gn_parts(d3, g)
+    assert parts > 0
+    y, partial = K.conv2d_f16x2(x, K.split_weight_f16x2(K.pack_conv_weight(w3)), b3, d3, gn_groups=g, gn_parts=parts)
+    res = K.conv2d_f16x2(x, K.split_weight_f16x2(K.pack_conv_weight(w1)), b1, d1, measure_out=True)
+    assert getattr(res, "_mf_slots", None) is not None and getattr(res, "_mf_bound", None) is None
+    bc = float(gamma.abs().max()) * (h * w * co // g) ** 0.5 + float(beta.abs().max())
+    a = K.gn_apply(y, K.GnPartials(partial, parts, 1e-5), gamma, beta, g, 1, res, split=True, bconst=bc)      # slots reduced inside the pass
+    assert getattr(res, "_mf_bound", None) is None
+    want_bound = bc + res.abs().amax(dim=(1, 2, 3))
+    assert torch.equal(a._mf_bound, want_bound)
+    assert torch.equal(K.bound_of(res), res.abs().amax(dim=(1, 2, 3)))                                       # lazily finalised on demand
+    b = K.gn_apply(y, K.gn_finalize(partial, parts, h * w, co, g), gamma, beta, g, 1, res, split=True, bconst=bc)
+    assert relerr(a, b) < 2e-7 and torch.equal(a._mf_bound, b._mf_bound)
+    assert torch.equal(a._mf_split, K.split_f16x2(a, a._mf_bound))
