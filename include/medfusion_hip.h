@@ -225,6 +225,10 @@ typedef struct MfSchedArgs {
 int mf_sched_step_f32(const MfSchedArgs* a, void* stream);
 /* out[0..n) = table[step] with step = *step_dev (or `step`): `t.expand(B)` of diffusion_pipeline.py:294 inside a captured graph */
 int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int32_t step, float* out, int n, void* stream);
+/* out[b][:] = table[step][cols[b]][:] for a [S][ncol][row_len] table, step = *step_dev (or `step`): the per-iteration gather of the
+ * embedding rows UNet.precompute_embeddings hoisted out of the loop (unet2.py:229-241, conv_blocks.py:340-353), usable inside a captured graph. */
+int mf_gather_step_rows_f32(const float* table, const int64_t* cols, const int32_t* step_dev, int32_t step, int ncol, int64_t row_len,
+                            float* out, int B, void* stream);
 /* *counter += inc (one thread); lets a captured graph advance its own step index. */
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream);
 

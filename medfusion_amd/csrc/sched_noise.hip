@@ -69,6 +69,18 @@ __global__ __launch_bounds__(256) void sched_step_kernel(const MfSchedArgs a) {
   }
 }
 
+// out[b][0..row_len) = table[(step * ncol + cols[b]) * row_len ...): the rows of loop iteration `step` (device counter or host value) of a
+// [S][ncol][row_len] table, one table column per batch row.  float4 when row_len % 4 == 0.
+__global__ __launch_bounds__(256) void gather_step_rows_kernel(const float* __restrict__ table, const long* __restrict__ cols,
+                                                               const int* __restrict__ step_dev, int step, int ncol, long row_len,
+                                                               float* __restrict__ out, long total) {
+  const long st = step_dev ? (long)*step_dev : (long)step;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / row_len, k = i - b * row_len;
+    out[i] = table[((st * ncol) + cols[b]) * row_len + k];
+  }
+}
+
 __global__ void broadcast_from_table_kernel(const float* __restrict__ table, const int32_t* __restrict__ step_dev, int step, float* __restrict__ out, int n) {
   const int st = step_dev ? *step_dev : step;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,6 +151,17 @@ int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int
   MF_REQUIRE(table && out && n > 0, MF_EINVAL, "broadcast_from_table: bad args");
   hipLaunchKernelGGL(broadcast_from_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, step_dev, step, out, n);
   return check_launch("broadcast_from_table");
+}
+
+int mf_gather_step_rows_f32(const float* table, const int64_t* cols, const int32_t* step_dev, int32_t step, int ncol, int64_t row_len, float* out,
+                            int B, void* stream) {
+  MF_REQUIRE(table && cols && out && ncol > 0 && row_len > 0 && B > 0, MF_EINVAL, "gather_step_rows: bad args");
+  const long total = (long)B * row_len;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gather_step_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, table, reinterpret_cast<const long*>(cols), step_dev,
+                     step, ncol, (long)row_len, out, total);
+  return check_launch("gather_step_rows");
 }
 
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream) {

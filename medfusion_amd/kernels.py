@@ -429,6 +429,19 @@ def sched_step(args: L.MfSchedArgs) -> None:
     L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
 
 
+def gather_step_rows(table: torch.Tensor, step, cols: torch.Tensor) -> torch.Tensor:
+    """table [S, NCOL, L] fp32, cols [B] int64 -> [B, L] = table[step, cols[b]]; `step`: a host int or a device int32 counter (graph replay)"""
+    _gpu(table, cols)
+    s_, ncol, ln = table.shape
+    assert table.is_contiguous() and cols.dtype == torch.int64 and cols.is_contiguous()
+    out = torch.empty((cols.shape[0], ln), dtype=torch.float32, device=table.device)
+    dev_step = isinstance(step, torch.Tensor)
+    rc = L.load().mf_gather_step_rows_f32(table.data_ptr(), cols.data_ptr(), step.data_ptr() if dev_step else None, 0 if dev_step else int(step), ncol, ln,
+                                          out.data_ptr(), cols.shape[0], stream())
+    L.check(rc, "mf_gather_step_rows_f32")
+    return out
+
+
 def broadcast_from_table(table: torch.Tensor, step_dev: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     _gpu(table, step_dev, out)
     L.check(L.load().mf_broadcast_from_table_f32(table.data_ptr(), step_dev.data_ptr(), 0, out.data_ptr(), out.numel(), stream()), "mf_broadcast_from_table_f32")

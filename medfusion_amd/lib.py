@@ -72,6 +72,7 @@ _SIGS = {
     "mf_embedding_add_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
     "mf_sched_step_f32": (_I, [C.POINTER(MfSchedArgs), c_fp]),
     "mf_broadcast_from_table_f32": (_I, [c_fp, c_fp, C.c_int32, c_fp, _I, c_fp]),
+    "mf_gather_step_rows_f32": (_I, [c_fp, c_fp, c_fp, C.c_int32, _I, _I64, c_fp, _I, c_fp]),
     "mf_rows_axpby_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I, _I64, _I, _F, _F, c_fp]),
     "mf_image_egress_u8": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, _I, _I, c_fp]),
     "mf_counter_add_i32": (_I, [c_fp, C.c_int32, c_fp]),

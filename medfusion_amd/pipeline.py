@@ -203,17 +203,7 @@ class DiffusionPipeline(nn.Module):
             x0 = torch.empty_like(x_t)
             self_cond = None
             est = self._estimator()
-            emb_tab = None
-            if self.hoist_embeddings and hasattr(est, "can_precompute_embeddings") and est.can_precompute_embeddings():
-                # all timesteps are known: the embedding path leaves the loop (UNet.precompute_embeddings; bit-identical)
-                has_c = est.cond_embedder is not None
-                used = set()   # labels that occur in this loop (one host read before the loop starts)
-                for lab in (condition, un_cond):
-                    if has_c and lab is not None:
-                        used.update(int(v) for v in lab.reshape(-1).tolist())
-                tab = est.precompute_embeddings(t_all[:, 0].contiguous(), classes=used if has_c else None)
-                emb_tab = (tab, est.embedding_columns(condition if has_c else None, B, dev, tab),
-                           est.embedding_columns(un_cond if has_c else None, B, dev, tab))
+            emb_tab = self._hoisted_embeddings(est, t_all[:, 0].contiguous(), condition, un_cond, B, dev)
             for i in range(len(rev)):
                 pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond,
                                                             emb=None if emb_tab is None else (emb_tab[0], i, emb_tab[1], emb_tab[2]))
@@ -232,6 +222,19 @@ class DiffusionPipeline(nn.Module):
         if decode and self.latent_embedder is not None:
             x_t = self.latent_embedder.decode(x_t)
         return x_t
+
+    def _hoisted_embeddings(self, est, t_steps, condition, un_cond, B, dev):
+        """All timesteps of a loop are known before it starts: the embedding path leaves the loop (UNet.precompute_embeddings; bit-identical
+        to evaluating it per iteration).  -> (table, columns of `condition`, columns of `un_cond`) or None when the estimator cannot."""
+        if not (self.hoist_embeddings and hasattr(est, "can_precompute_embeddings") and est.can_precompute_embeddings()):
+            return None
+        has_c = est.cond_embedder is not None
+        used = set()   # labels that occur in this loop (one host read before the loop starts)
+        for lab in (condition, un_cond):
+            if has_c and lab is not None:
+                used.update(int(v) for v in lab.reshape(-1).tolist())
+        tab = est.precompute_embeddings(t_steps, classes=used if has_c else None)
+        return (tab, est.embedding_columns(condition if has_c else None, B, dev, tab), est.embedding_columns(un_cond if has_c else None, B, dev, tab))
 
     def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective):
         """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]).  Everything the
@@ -252,9 +255,12 @@ class DiffusionPipeline(nn.Module):
         base = noise.draw_index  # draws consumed so far (x_T)
         clip, g = int(bool(self.clip_x0)), float(guidance_scale)
 
+        emb_tab = self._hoisted_embeddings(self._estimator(), t_table, condition, un_cond, B, dev)
+        emb = None if emb_tab is None else (emb_tab[0], step_dev, emb_tab[1], emb_tab[2])   # rows of iteration *step_dev, gathered on the device
+
         def body():
             K.broadcast_from_table(t_table, step_dev, t_cur)
-            pred, pred_uncond, pred_var = self._predict(x_t, t_cur, condition, None if not self.use_self_conditioning else x0, g, un_cond)
+            pred, pred_uncond, pred_var = self._predict(x_t, t_cur, condition, None if not self.use_self_conditioning else x0, g, un_cond, emb=emb)
             noise.draw_indexed(n_post, base, stride, step_dev)
             if use_ddim:
                 noise.draw_indexed(n_ddim, base + 1, stride, step_dev)
@@ -271,7 +277,7 @@ class DiffusionPipeline(nn.Module):
             # Q11: with self-conditioning the first call sees self_cond=None -> run it eagerly in that form
             if self.use_self_conditioning:
                 K.broadcast_from_table(t_table, step_dev, t_cur)
-                pred, pu, pv = self._predict(x_t, t_cur, condition, None, g, un_cond)
+                pred, pu, pv = self._predict(x_t, t_cur, condition, None, g, un_cond, emb=emb)
                 noise.draw_indexed(n_post, base, stride, step_dev)
                 if use_ddim:
                     noise.draw_indexed(n_ddim, base + 1, stride, step_dev)

@@ -232,10 +232,10 @@ class UNet(nn.Module):
                 lut[c] = 1 + k
         emb = torch.stack(cols, dim=1).contiguous()                                     # [S, NCOL, E]  (plumbing)
         w, b = self._packed_local_embedders()
-        local = K.linear(emb.view(S * len(cols), -1), w, b, act_in=True).view(S, len(cols), -1)
+        local = K.linear(emb.view(S * len(cols), -1), w, b, act_in=True).view(S, len(cols), -1).contiguous()
         table = {"emb": emb, "local": local, "need_emb": any(isinstance(m, Attention) for m in self.modules()), "lut": lut}
         if BLK.f16x2_mode():  # bound of every embedding row, once (operand scaling of the fp16-pair mode)
-            table["local_bound"] = K.maxabs_rows(local.view(S * len(cols), -1)).view(S, len(cols))
+            table["local_bound"] = K.maxabs_rows(local.view(S * len(cols), -1)).view(S, len(cols), 1).contiguous()
         return table
 
     @staticmethod
@@ -249,12 +249,13 @@ class UNet(nn.Module):
         return lab + 1
 
     @staticmethod
-    def step_embeddings(table, i: int, cols: torch.Tensor):
-        """(emb [B,E] | None, local_all [B, sum Cout]) of loop iteration i for rows with table columns `cols` (a gather: plumbing)"""
-        emb = table["emb"][i].index_select(0, cols) if table["need_emb"] else None
-        local = table["local"][i].index_select(0, cols)
+    def step_embeddings(table, i, cols: torch.Tensor):
+        """(emb [B,E] | None, local_all [B, sum Cout]) of loop iteration i for rows with table columns `cols`.
+        i: a host int, or the device int32 step counter of a captured graph (mf_gather_step_rows_f32 reads it on the device)."""
+        emb = K.gather_step_rows(table["emb"], i, cols) if table["need_emb"] else None
+        local = K.gather_step_rows(table["local"], i, cols)
         if "local_bound" in table:
-            local._mf_bound = table["local_bound"][i].index_select(0, cols)
+            local._mf_bound = K.gather_step_rows(table["local_bound"], i, cols).view(-1)
         return emb, local
 
     @torch.no_grad()
