@@ -139,7 +139,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--ddim-steps", type=int, default=None, help="override the number of denoise iterations (non-headline)")
-    ap.add_argument("--graph", action="store_true", help="replay the denoise iteration as a captured hipGraph (default for cfg4)")
+    ap.add_argument("--graph", action="store_true", help="force replaying the denoise iteration as a captured hipGraph (default: decided by denoise() from the problem size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--conv-precision", type=int, default=None, choices=sorted(ARITH),
@@ -177,8 +177,8 @@ def main():
     pipe = P.build_published_pipeline(dev, wl["classes"])
     cond = (torch.arange(n_global, device=dev) % wl["classes"]) if wl["classes"] else None
     kw = dict(steps=wl["steps"], use_ddim=wl["use_ddim"])
-    if args.graph or args.workload == "cfg4":
-        kw["use_graph"] = True
+    if args.graph:
+        kw["use_graph"] = True    # (default: denoise() decides -- graph replay only while the host would be the bottleneck)
     if cond is not None:
         kw.update(guidance_scale=wl["guidance"], un_cond=None)
 
