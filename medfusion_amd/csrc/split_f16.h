@@ -48,14 +48,20 @@ __device__ __forceinline__ void split8_f16(const sf_f32x4 v0, const sf_f32x4 v1,
   lo = sf_u32x4{l0, l1, l2, l3};
 }
 // 4 consecutive channels starting at element index e (a multiple of 4) of a tensor whose innermost extent is a multiple of 8;
-// sc = 2^-s of the sample the element belongs to
+// sc = 2^-s of the sample the element belongs to.  PRECONDITION: lanes 2k and 2k+1 of the wave hold the two halves of the same 8-channel
+// group and both execute the call (thread index == float4 index modulo an even stride, even float4 count): the pair swaps one 8-byte
+// piece through DPP so that each lane stores ONE full 16-byte slot ([hi x 8] by the even lane, [lo' x 8] by the odd one) -- a wave
+// writes 1 KB contiguously with one instruction instead of two half-filled ones.
 __device__ __forceinline__ void store_split4(void* ys, long e, float a, float b, float c, float d, float sc) {
   unsigned h0, h1, l0, l1;
   split2_f16(a * sc, b * sc, h0, l0);
   split2_f16(c * sc, d * sc, h1, l1);
-  sf_u32x2* o = reinterpret_cast<sf_u32x2*>(ys) + (e >> 3) * 4 + ((e >> 2) & 1);
-  o[0] = sf_u32x2{h0, h1};
-  o[2] = sf_u32x2{l0, l1};
+  const bool odd = (e >> 2) & 1;
+  const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;                          // what the partner stores
+  const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+  const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
+  const sf_u32x4 v = odd ? sf_u32x4{r0, r1, l0, l1} : sf_u32x4{h0, h1, r0, r1};
+  reinterpret_cast<sf_u32x4*>(ys)[(e >> 3) * 2 + (odd ? 1 : 0)] = v;
 }
 
 // Measured bounds: thousands of waves updating the same few words with atomics serialise on one L2 channel (measured: 66 us for a 10 us
