@@ -223,12 +223,21 @@ def main():
         alg = fl / (ms * 1e-3) / 1e12     # algorithmic FLOPs of the reference convolutions / their launch time
         exe = ex / (ms * 1e-3) / 1e12     # FLOPs the matrix pipe executes: terms per product x the MACs actually done (sub-pixel up-convs: 4/9)
         traffic, traffic_src = pmc_traffic(ar["pmc_match"])
+        sustained = None
+        if ar["peak"] > 1000:   # the 16-bit matrix pipe: what it sustains on THIS device with nothing but MFMAs in flight, by operand data
+            rnd, zer = K.mfma_sustained_tflops(dev, "random"), K.mfma_sustained_tflops(dev, "zeros")
+            sustained = {"random_operands_tflops": round(rnd, 1), "zero_operands_tflops": round(zer, 1),
+                         "how": "mf_mfma_rate_probe_f16 live on this device: v_mfma_f32_32x32x16_f16 from registers only, 4 chains per wave, 2 waves "
+                                "per SIMD, one workgroup per CU, 0.6 ms bursts, best of 3 (scripts/mfma_power_probe.hip, "
+                                "profiles/r02_mfma_power_probe.txt): the pipe is power-limited by the data it multiplies"}
         hbm = {}
         for fam in ("gn_apply", "splitk_reduce", "gn_stats", "sched", "noise"):
             if fam in tab and tab[fam][0] > 0:
                 hbm[fam] = {"ms": round(tab[fam][0], 3), "launches": int(tab[fam][1]), "algorithmic_GBps": round(tab[fam][3] / (tab[fam][0] * 1e-3) / 1e9, 1)}
         roof = {"bound": "mfma", "kernel": f"{ar['kernel']} -- {ar['text']}",
                 "achieved": round(exe, 2), "peak": round(ar["peak"], 1), "unit": "TFLOP/s", "frac": round(exe / ar["peak"], 4),
+                "mfma_sustained": sustained,
+                "frac_of_sustained_random_operands": None if sustained is None else round(exe / sustained["random_operands_tflops"], 4),
                 "frac_is": "EXECUTED matrix flops of the implicit-GEMM conv kernel / the dense MFMA peak of the pipe it runs on "
                            f"({ar['terms']} matrix term(s) per product)",
                 "algorithmic_tflops": round(alg, 2),

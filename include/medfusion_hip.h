@@ -288,6 +288,12 @@ int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, doub
 /* the same plus the flops the hardware EXECUTES for those launches (matrix terms per product x the MACs actually done) */
 int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, double* bytes, double* exec_flops);
 const char* mf_prof_family_name(int family);
+/* Measurement aid: what the fp16 matrix pipe SUSTAINS on this device for given operand data.  Launches `workgroups` x 512 threads running
+ * nothing but v_mfma_f32_32x32x16_f16 from registers (4 independent chains per wave, `iters` instructions per chain; operands = the first
+ * workgroups * 512 * 8 sixteen-byte groups of fp16 at `operands`, loaded once; `out`: workgroups * 512 floats) and reports the flops of the
+ * launch; the caller times it.  On MI355X random operands sustain ~60-65 % of the nominal 2516.8 TF, zeros ~97 % (profiles/): the matrix
+ * pipe is power-limited by the data it multiplies, and bench.py reports the conv kernel against both numbers. */
+int mf_mfma_rate_probe_f16(const void* operands, float* out, int workgroups, int iters, double* flops, void* stream);
 
 #ifdef __cplusplus
 }

@@ -57,6 +57,34 @@ ProfScope::~ProfScope() {
 
 using namespace mf;
 
+namespace {
+typedef float pr_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 pr_f16x8 __attribute__((ext_vector_type(8)));
+// nothing but v_mfma_f32_32x32x16_f16 from registers: 4 independent chains per wave, operands loaded once (mf_mfma_rate_probe_f16)
+__global__ __launch_bounds__(512) void mfma_rate_probe_kernel(const pr_f16x8* __restrict__ in, float* __restrict__ out, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  pr_f16x8 a[4], b[4];
+  pr_f32x16 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    a[k] = in[(size_t)tid * 8 + 2 * k];
+    b[k] = in[(size_t)tid * 8 + 2 * k + 1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k], b[k], acc[k], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[k][r];
+  out[tid] = s;
+}
+}  // namespace
+
 extern "C" {
 
 int mf_version(void) { return MF_VERSION; }
@@ -113,6 +141,13 @@ const char* mf_prof_family_name(int f) {
   static const char* names[MF_FAM_COUNT] = {"conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply",
                                             "linear", "sched", "noise", "attention", "misc"};
   return (f >= 0 && f < MF_FAM_COUNT) ? names[f] : "?";
+}
+
+int mf_mfma_rate_probe_f16(const void* operands, float* out, int workgroups, int iters, double* flops, void* stream) {
+  MF_REQUIRE(operands && out && workgroups > 0 && iters > 0, MF_EINVAL, "mfma_rate_probe: bad args");
+  hipLaunchKernelGGL(mfma_rate_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<const pr_f16x8*>(operands), out, iters);
+  if (flops) *flops = (double)workgroups * 8.0 * 4.0 * (double)iters * 32768.0;
+  return check_launch("mfma_rate_probe");
 }
 
 }  // extern "C"

@@ -541,3 +541,25 @@ class prof:
             if n.value:
                 out[name] = (ms.value, n.value, fl.value, by.value, ex.value)
         return out
+
+
+def mfma_sustained_tflops(device, data: str = "random", iters: int = 4000, reps: int = 3) -> float:
+    """TFLOP/s the fp16 matrix pipe sustains on `device` with nothing but MFMAs in flight (mf_mfma_rate_probe_f16), operands "random"
+    (N(0,1) as fp16) or "zeros": the measured ceiling bench.py sets next to the nominal peak."""
+    wgs = torch.cuda.get_device_properties(device).multi_processor_count
+    n = wgs * 512 * 8 * 8
+    ops = (torch.randn((n,), device=device, generator=torch.Generator(device=device).manual_seed(1)) if data == "random"
+           else torch.zeros((n,), device=device)).to(torch.float16)
+    out = torch.empty((wgs * 512,), dtype=torch.float32, device=device)
+    fl = C.c_double(0.0)
+    lib = L.load()
+    best = 0.0
+    for r in range(reps + 1):   # first launch: warm-up of the same length
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.mf_mfma_rate_probe_f16(ops.data_ptr(), out.data_ptr(), wgs, iters, C.byref(fl), stream()), "mf_mfma_rate_probe_f16")
+        e1.record()
+        e1.synchronize()
+        if r:
+            best = max(best, fl.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best

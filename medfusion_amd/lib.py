@@ -89,6 +89,7 @@ _SIGS = {
     "mf_prof_query": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mf_prof_query2": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mf_prof_family_name": (C.c_char_p, [_I]),
+    "mf_mfma_rate_probe_f16": (_I, [c_fp, c_fp, _I, _I, C.POINTER(C.c_double), c_fp]),
 }
 
 _lib = None
