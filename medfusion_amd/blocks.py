@@ -121,20 +121,21 @@ class Conv(nn.Module):
         if ent is None:
             d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=5)
             ok = K.conv_f16x2_ok(d)
-            ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok)
+            pinned = K.pin_conv_plan(d) if ok else None     # (tile, split-K) fixed in the descriptor: per-launch planning is a field read
+            ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok, pinned)
             self._descs[key] = ent
-        d, parts, ok = ent
+        d, parts, ok, pinned = ent
         if not ok:
             return None
         pk = self._packed_sub if d.upsample == 2 else self._packed
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
-            return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, measure_out=measure_out)
+            return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, measure_out=measure_out, pinned=pinned)
         ho, wo = K.conv_out_hw(d)
         if parts > 0:
-            y, partial = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, gn_groups=gn_groups, gn_parts=parts)
+            y, partial = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, gn_groups=gn_groups, gn_parts=parts, pinned=pinned)
         else:
-            y = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out)
+            y = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, pinned=pinned)
             partial, parts = K.gn_stats_partial(y, gn_groups)
         # the apply pass reduces the records itself (mf_gn_apply_from_partials_f32: 30.5 vs 30.3 images/s against a finalize launch per norm)
         return y, K.GnPartials(partial, parts, gn_eps)

@@ -27,8 +27,16 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def stream(device_index: Optional[int] = None) -> int:
+    """the hipStream_t torch launches on right now (current device, or `device_index`): the raw C entry points when this torch has them --
+    `torch.cuda.current_stream()` builds a Stream object per call, a quarter of the host time of a launch (scripts/host_profile.py)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device() if device_index is None else device_index)
+    return (torch.cuda.current_stream() if device_index is None else torch.cuda.current_stream(device_index)).cuda_stream
 
 
 class Workspace:
@@ -39,7 +47,7 @@ class Workspace:
 
     @classmethod
     def get(cls, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)  # per stream: concurrent streams must not share scratch
+        key = (device.index, stream(device.index))  # per stream: concurrent streams must not share scratch
         buf = cls._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():
@@ -175,10 +183,22 @@ def conv_plan(d: L.MfConvDesc):
     return t.value, k.value
 
 
+def pin_conv_plan(d: L.MfConvDesc):
+    """Fix the planner's choice for `d` in its hint fields (later calls with this descriptor skip the table lookup and the cost model) and
+    return what a caller needs per launch: (workspace bytes, slots of the measured-bound array)."""
+    lib = L.load()
+    if d.precision == 5 and not (d.tile_hint and d.splitk_hint):
+        t, k = conv_plan(d)
+        if t > 0 and k > 0:
+            d.tile_hint, d.splitk_hint = t, k
+    return lib.mf_conv2d_workspace_bytes(C.byref(d)), (lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if d.precision == 5 else 0)
+
+
 def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None, measure_out: bool = False, gn_groups: int = 0, gn_parts: int = 0):
+                 out: Optional[torch.Tensor] = None, measure_out: bool = False, gn_groups: int = 0, gn_parts: int = 0, pinned=None):
     """MF_CONV_FP32_F16X2 convolution of fp32 NHWC tensors whose fp16-pair mirrors are made on demand.  w_split = split_weight_f16x2(...).
     measure_out: also measure the per-sample max |y| (-> y._mf_bound: the output feeds a convolution or a residual add un-normalised).
+    pinned: pin_conv_plan(d), computed once by callers that launch the same descriptor every iteration.
     Returns y, or (y, partial [N, parts, G, 2]) when gn_groups > 0 (statistics of the GroupNorm that follows)."""
     wh, wmax = w_split
     _gpu(x1, x2, wh, bias)
@@ -190,10 +210,13 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
         out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
     else:
         drop_split(out)
-    slots = lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if measure_out and not gn_groups else 0
+    if pinned is None:
+        pinned = (lib.mf_conv2d_workspace_bytes(C.byref(d)), lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if measure_out and not gn_groups else 0)
+    need, slots = pinned
+    if not measure_out or gn_groups:
+        slots = 0
     yb = torch.empty((d.N, slots), dtype=torch.float32, device=x1.device) if slots else None
     partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=x1.device) if gn_groups else None
-    need = lib.mf_conv2d_workspace_bytes(C.byref(d))
     ws = Workspace.get(need, x1.device) if need else None
     rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), wmax, _ptr(yb), _ptr(ws), need,
                              _ptr(partial), gn_groups, C.byref(d), stream())

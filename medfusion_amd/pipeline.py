@@ -163,13 +163,14 @@ class DiffusionPipeline(nn.Module):
         if use_graph and trace is not None:
             raise ValueError("use_graph=True cannot record a trace (the captured step is replayed, nothing returns to the host)")
         if use_graph is None:
-            # Replaying the iteration as a captured hipGraph removes the host's 2.4 ms of launch work per iteration but dispatches every
-            # kernel node ~1 us later than a stream-ordered launch (profiles/r02_host_enqueue_time.txt: B=1 256 vs 362 ms per 150
-            # iterations, B=4 334 vs 357, B=8 391 vs 369, B=16 535 vs 508): worth it only while the host is the bottleneck.
+            # Replaying the iteration as a captured hipGraph removes the host's 2.0 ms of launch work per iteration but dispatches every
+            # kernel node ~1 us later than a stream-ordered launch (profiles/r02_host_enqueue_time.txt, ms per 150 iterations, graph vs
+            # eager: B=1 at 8x8 254 vs 298, B=4 at 32x32 337 vs 321, B=8 392 vs 371, B=16 538 vs 512): worth it only while the host
+            # is the bottleneck.
             from .noise import PhiloxDeviceNoise
             rows = x_t.shape[0] * (2 if (condition is not None and guidance_scale != 1.0) else 1)
             use_graph = (trace is None and not cold_diffusion and (noise is None or isinstance(noise, PhiloxDeviceNoise))
-                         and rows * x_t.shape[-1] * x_t.shape[-2] <= 4 * 32 * 32 and (steps is None or steps >= 8))
+                         and rows * x_t.shape[-1] * x_t.shape[-2] <= 2 * 32 * 32 and (steps is None or steps >= 8))
         sch = self.noise_scheduler
         dev = x_t.device
         B = x_t.shape[0]
