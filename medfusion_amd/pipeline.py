@@ -149,6 +149,12 @@ class DiffusionPipeline(nn.Module):
                 **kwargs):
         """diffusion_pipeline.py:278-310.  kwargs: guidance_scale, un_cond, cold_diffusion (forwarded to forward()
         by the reference); `eta` raises like the reference's forward() would (Q2)."""
+        if not x_t.is_cuda:
+            raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
+        with torch.cuda.device(x_t.device):   # (see sample())
+            return self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs)
+
+    def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs):
         if "eta" in kwargs:
             raise TypeError("forward() got an unexpected keyword argument 'eta'")
         guidance_scale = kwargs.pop("guidance_scale", 1.0)
@@ -326,9 +332,10 @@ class DiffusionPipeline(nn.Module):
                 kwargs["un_cond"] = kwargs["un_cond"][lo:hi]
         if noise is None:
             noise = default_noise()
-        noise.begin(hi - lo, dev, sample_offset=lo, global_batch=num_samples)
-        x_T = noise.draw((hi - lo, *img_size))  # noise_scheduler.x_final(template): draw #0 (Q3)
-        return self.denoise(x_T, condition=condition, noise=noise, **kwargs)
+        with torch.cuda.device(dev):   # launches go to the CURRENT device's stream: make the pipeline's device current for the call
+            noise.begin(hi - lo, dev, sample_offset=lo, global_batch=num_samples)
+            x_T = noise.draw((hi - lo, *img_size))  # noise_scheduler.x_final(template): draw #0 (Q3)
+            return self.denoise(x_T, condition=condition, noise=noise, **kwargs)
 
     @torch.no_grad()
     def interpolate(self, img1, img2, i=None, condition=None, lam=0.5, noise: Optional[NoiseSource] = None, **kwargs):

@@ -376,7 +376,7 @@ def test_four_channel_latent_model_family(dev):
 @torch.no_grad()
 def test_cfg5_512px_shape_properties(dev, published):
     """configs[4]: latent (8,64,64) -> 512x512 on the published widths.  One UNet evaluation + decode vs the oracle at B=1
-    (the oracle needs ~10 s on CPU), then row independence at B=4."""
+    (the oracle needs ~10 s on CPU), then determinism, row independence and a decode at the per-GPU workload (32 images over 4 GPUs = 8 rows)."""
     ora, pipe = published
     x = S.synth_input("cfg5_x", (1, 8, 64, 64))
     t = torch.tensor([250])
@@ -386,9 +386,13 @@ def test_cfg5_512px_shape_properties(dev, published):
     img = pipe.latent_embedder.decode(x.to(dev))
     assert img.shape == (1, 3, 512, 512)
     assert relerr(img, ora.latent_embedder.decode(x)) < TOL
-    full = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False)
-    one = pipe.sample(4, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False, shard=(2, 4))
+    full = pipe.sample(8, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False)
+    assert torch.equal(full, pipe.sample(8, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False))
+    one = pipe.sample(8, (8, 64, 64), steps=2, use_ddim=True, noise=M.PhiloxDeviceNoise(9), decode=False, shard=(2, 8))
     assert relerr(one, full[2:3]) < 1e-5
+    imgs = pipe.latent_embedder.decode(full)
+    assert imgs.shape == (8, 3, 512, 512) and bool(imgs.isfinite().all())
+    assert relerr(imgs[5:6], pipe.latent_embedder.decode(full[5:6])) < 1e-5
 
 
 @torch.no_grad()
