@@ -57,7 +57,7 @@ ARITH = {
 def self_launch(args) -> int:
     """`python bench.py --gpus N` outside a launcher: become N ranks under torch.distributed.run on this node."""
     n_vis = torch.cuda.device_count()
-    if n_vis < args.gpus:
+    if n_vis < args.gpus and os.environ.get("MEDFUSION_BENCH_SHARE_GPU") != "1":
         print(f"bench.py: --gpus {args.gpus} requested but only {n_vis} ROCm device(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as s:
@@ -161,9 +161,14 @@ def main():
     if args.conv_precision is not None:
         BLK.CONV_PRECISION = args.conv_precision
     prec = BLK.CONV_PRECISION
-    rank, local, world = D.init_from_env()
+    # MEDFUSION_BENCH_SHARE_GPU=1 (tests on a 1-GPU box only): every rank uses device 0 and the group runs over gloo -- exercises the whole
+    # N > 1 code path (sharding, fences, MAX over ranks, gather, teardown); the line it prints says so in `parallelism`
+    share = os.environ.get("MEDFUSION_BENCH_SHARE_GPU") == "1"
+    rank, local, world = D.init_from_env("gloo" if share else None)
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
+    if share:
+        local = 0
     if torch.cuda.device_count() < (local + 1 if world > 1 else 1):
         raise SystemExit(f"bench.py: rank {rank} needs device {local}, {torch.cuda.device_count()} visible")
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -198,7 +203,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert img.shape[0] == n_global and bool(torch.isfinite(img).all())
@@ -275,7 +280,7 @@ def main():
             "data": "synthetic (seeded weights of the published architecture, device Philox noise)",
             "config": {"workload": f"{args.workload}: {B} images/GPU, latent {wl['latent']}, {wl['steps']} {'DDIM' if wl['use_ddim'] else 'DDPM'} iterations, "
                                    f"{'uncond' if cond is None else 'cond %d-class g=%s' % (wl['classes'], wl['guidance'])}, decode to {8 * wl['latent'][1]}x{8 * wl['latent'][2]}",
-                       "global_batch": n_global, "parallelism": f"dp{world} (batch rows sharded, 1 all-gather of images)"},
+                       "global_batch": n_global, "parallelism": f"dp{world} (batch rows sharded, 1 all-gather of images)" + (" -- TEST MODE: ranks share one GPU, gloo" if share else "")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if alts:
@@ -285,6 +290,7 @@ def main():
             out["whole_path_frac_of_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()   # rank 0 has been profiling on its own: every rank leaves the group together
         dist.destroy_process_group()
 
 

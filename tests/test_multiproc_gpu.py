@@ -97,3 +97,16 @@ def test_bench_launches_its_own_ranks_or_refuses_loudly(tmp_path):
         assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32
     else:
         assert r.returncode == 2 and "visible" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """the whole N > 1 path of bench.py (self-launch under torch.distributed.run, sharded sample, fences, MAX over ranks, gather, teardown) with
+    two ranks sharing device 0 over gloo (MEDFUSION_BENCH_SHARE_GPU=1: a test switch, the printed line says so)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MEDFUSION_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--ddim-steps", "2", "--batch", "2", "--no-cpu-baseline",
+                        "--no-alt-path"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["value"] > 0 and "TEST MODE" in line["config"]["parallelism"]
+    assert line["roofline"] is not None and line["roofline"]["launches"] > 0
