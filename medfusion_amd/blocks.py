@@ -282,36 +282,8 @@ class BasicResBlock(nn.Module):
             if isinstance(x, (tuple, list)) or in_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("identity residual needs a single NHWC input")
             return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
-        if not SIDE_STREAM_RESIDUAL:
-            res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
-            return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
-        # The 1x1 residual conv and the 3x3 conv read the same input and are independent: run the small one on a side
-        # stream so its ramp-up/drain overlaps the big one (fork/join; works under graph capture too).
-        cur = torch.cuda.current_stream()
-        side = _side_stream(cur.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            res = self.conv_res(x, in_layout=in_layout)
-        y_partial = self.basic_block.conv_and_stats(x, in_layout=in_layout)
-        cur.wait_stream(side)
-        for t in (_split(x)):
-            if t is not None:
-                t.record_stream(side)
-        res.record_stream(cur)
-        return self.basic_block.finish(y_partial, residual=res, emb=emb, emb_stride=emb_stride)
-
-
-SIDE_STREAM_RESIDUAL = False  # experiment: measured SLOWER on MI355X (13.26 vs 13.52 img/s at cfg2, scripts/ab_side_stream.py) -> off
-_SIDE = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    s = _SIDE.get(key)
-    if s is None:
-        s = torch.cuda.Stream(device=device)
-        _SIDE[key] = s
-    return s
+        res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
+        return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
 
 
 class _EmbBlock(nn.Module):
