@@ -138,7 +138,9 @@ class Conv(nn.Module):
             y = K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, pinned=pinned)
             partial, parts = K.gn_stats_partial(y, gn_groups)
         # the apply pass reduces the records itself (mf_gn_apply_from_partials_f32: 30.5 vs 30.3 images/s against a finalize launch per norm)
-        return y, K.GnPartials(partial, parts, gn_eps)
+        if gn_groups <= 256:
+            return y, K.GnPartials(partial, parts, gn_eps)
+        return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)   # (more groups than a workgroup has threads)
 
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
                 gn_eps: float = 1e-5, measure_out: bool = False):
