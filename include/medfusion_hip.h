@@ -104,14 +104,20 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
  *   doubles, parts = mf_conv2d_gn_parts(d, G) > 0.  y_bound optional ([N][slots] floats, slots = mf_conv2d_f16x2_bound_slots(d) > 0,
  *   not together with gn_partial): every (tile, wave) -- or reducer wave -- stores the max |y| of its share of a sample; reduce with
  *   mf_bound_finalize_f32 to the operand bound of y for consumers that take it un-normalised.  Split-K plans reduce through `workspace`
- *   (mf_conv2d_workspace_bytes), the reducer emitting y, the statistics and y_bound.
+ *   (mf_conv2d_workspace_bytes).  A power-of-two split meets INSIDE the launch: the partial tiles of a pair are handed over through
+ *   `workspace` with write-through stores, a counter per pair in `sync` tells the workgroup that arrives second to add its partner's tile
+ *   (a + b does not depend on who adds: deterministic), the last one runs the ordinary epilogue -- no reducer launch.  `sync`:
+ *   mf_conv2d_f16x2_sync_words(d) 32-bit words, zero before the FIRST launch and left zero by every launch (caller keeps them; one array
+ *   per stream is enough).  Other splits (or GroupNorm statistics the epilogue cannot emit) take the slab + reducer pass, the reducer
+ *   emitting y, the statistics and y_bound.
  * mf_conv2d_plan_query: the tile id and split-K factor the planner picks for `d` (any precision; 0, 0 = not on the implicit-GEMM path). */
 int mf_conv2d_f16x2_ok(const MfConvDesc* d);
 int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d);
 int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64_t per_row, void* stream);
+int mf_conv2d_f16x2_sync_words(const MfConvDesc* d);
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound,
-                    const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, double* gn_partial, int G,
-                    const MfConvDesc* d, void* stream);
+                    const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync,
+                    double* gn_partial, int G, const MfConvDesc* d, void* stream);
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
 
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the

@@ -53,8 +53,14 @@ struct ConvP2 {
   long slab;
   unsigned bytes1, bytes2, bytesw;
   int subpix, hw_src;
-  double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1)
+  double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1, or tree)
   int gn_groups, gn_parts, gn_cpg;
+  // split-K reduced INSIDE the launch (tree != 0, splitk a power of two): the partial tiles meet pairwise, level by level; at every level
+  // both partners store their tile (write-through, agent scope), bump the pair's counter, and the one that arrives second adds its
+  // partner's tile and goes on -- a + b does not depend on who adds, so the result is deterministic.  The last one runs the epilogue.
+  int tree;
+  float* handoff;       // [tiles][2 (splitk - 1) slots][BM x BN floats]
+  unsigned* sync;       // [tiles][splitk - 1] counters, zero between launches (the second arriver of a pair resets its counter)
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; block b runs on XCD b % 8
@@ -353,15 +359,75 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   // All DMA has landed (the last iterations wait vmcnt(0)); the stages are dead once every wave has left the loop.
   MFC2_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
+  if (p.tree) {   // ---- split-K met inside the launch (see ConvP2)
+    // the accumulators become the values of this K slice, (main + cross / 2048) x 2^(operand scales); `accx` is cleared so that the
+    // epilogue below, which forms the same expression for the other launches, reproduces them (f_out = 1 there)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      MFC2_PIXEL_EXPS(i)
+      const float f_out = exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[i][j][r] = (accm[i][j][r] + accx[i][j][r] * kLoInv) * f_out; accx[i][j][r] = 0.f; }
+    }
+    constexpr int SLOT = BM * BN;                       // floats per hand-off slot; inside a slot: [wave][i][j][q][lane][4]
+    const int tile = tile_n * p.tiles_m + tile_m;
+    float* region = p.handoff + (long)tile * (2L * (p.splitk - 1)) * SLOT;
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(region, 0, (unsigned)(2 * (p.splitk - 1)) * (unsigned)SLOT * 4u, 0x00020000);
+    unsigned* cnt = p.sync + (long)tile * (p.splitk - 1);
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);   // (the pipeline stages are dead)
+    const unsigned lane_off = (unsigned)((wave * TM * TN * 4) * 64 + lane) * 16u;
+    int lbase = 0;
+    for (int span = 1; span < p.splitk; span <<= 1) {
+      const int lv = __builtin_ctz(span);
+      const int side = (kz >> lv) & 1, pair = kz >> (lv + 1);
+      const unsigned mine = (unsigned)(2 * (lbase + pair) + side) * (unsigned)SLOT * 4u, theirs = (unsigned)(2 * (lbase + pair) + (side ^ 1)) * (unsigned)SLOT * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(accm[i][j][4 * q + e]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), mine, 0x10);   // sc1: agent scope, write-through
+          }
+      MFC2_WAIT_VM(0);
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(cnt + lbase + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old) __hip_atomic_store(cnt + lbase + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // second: nobody touches it again in this launch
+        *flag = old;
+      }
+      __syncthreads();
+      const unsigned second = *flag;
+      __syncthreads();   // (the flag word is rewritten at the next level)
+      if (!second) return;            // the partner finishes this tile
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), theirs, 0x10);   // sc1: past this XCD's L2
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accm[i][j][4 * q + e] += __uint_as_float(v[e]);
+          }
+      lbase += p.splitk >> (lv + 1);
+    }
+  }
+  const bool last_slice = p.splitk == 1 || p.tree;   // this workgroup holds final values: bias, statistics, bounds
   constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [32 pixels][FN couts] fp32 (+16 B: conflict-free b128 writes)
   char* stg = smem + wave * (32 * PITCH);
   static_assert(NW * 32 * PITCH <= NST * STAGE, "epilogue staging must fit in the pipeline stages");
   constexpr int LPR = FN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;   // lanes per pixel row (8 couts each), rows per pass, passes per sub-tile
   const int rr = lane / LPR, c8 = lane % LPR;
   const int col0 = n0 + wn * FN + c8 * 8;
-  float* out = p.y + (p.splitk > 1 ? (long)kz * p.slab : 0L);
+  float* out = p.y + (last_slice ? 0L : (long)kz * p.slab);
   f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  if (p.splitk == 1 && p.bias) {
+  if (last_slice && p.bias) {
     b0 = *reinterpret_cast<const f32x4*>(p.bias + col0);
     b1 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4);
   }
@@ -369,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 #pragma unroll
   for (int i = 0; i < TM; ++i) {   // one 32-pixel sub-tile at a time through the wave's staging region (LDS operations of a wave stay in order)
     MFC2_PIXEL_EXPS(i)
-    const float f_out = exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
+    const float f_out = p.tree ? 1.f : exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll

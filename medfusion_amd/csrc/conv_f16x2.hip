@@ -131,12 +131,31 @@ int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
   return check_launch("conv_f16x2");
 }
 
+// split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
+// stays addressable with 32-bit offsets.  MF_CONV_TREE=0 keeps the reducer (A/B).
+bool tree_possible(const MfConvDesc* d, const Plan2& pl) {
+  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); return e ? atoi(e) : 1; }();
+  if (!(env & 1) || !pl.ok || pl.splitk < 2 || (pl.splitk & (pl.splitk - 1))) return false;
+  return 2.0 * (pl.splitk - 1) * pl.t.BM * pl.t.BN * 4.0 < 4294967040.0;
+}
+size_t tree_handoff_bytes(const MfConvDesc* d, const Plan2& pl) {
+  return (size_t)cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * 2u * (pl.splitk - 1) * pl.t.BM * pl.t.BN * sizeof(float);
+}
+// can the epilogue of the (last) workgroup of a tile emit the GroupNorm records: the tile lies inside one sample and holds whole groups
+bool epilogue_stats_ok(const MfConvDesc* d, const Plan2& pl, int G) {
+  const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
+  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); return e ? atoi(e) : 1; }();
+  if (pl.splitk > 1 && (env & 2)) return false;
+  return !(HW % pl.t.BM || pl.t.BN % cpg || cpg % 8);
+}
+
 // partial GroupNorm records the f16x2 convolution (or its split-K reducer) emits; 0: it cannot
 int gn_parts2(const MfConvDesc* d, const Plan2& pl, int G) {
   if (!pl.ok || G <= 0 || d->Cout % G) return 0;
-  const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
-  if (pl.splitk > 1) return stats_lds_bytes(d->Cout / stats_slices(d->N, HW, d->Cout, G)) <= 64 * 1024 ? stats_chunks(HW) : 0;
-  if (HW % pl.t.BM || pl.t.BN % cpg || cpg % 8) return 0;
+  const int HW = pl.Hout * pl.Wout;
+  if (pl.splitk > 1 && !(tree_possible(d, pl) && epilogue_stats_ok(d, pl, G)))
+    return stats_lds_bytes(d->Cout / stats_slices(d->N, HW, d->Cout, G)) <= 64 * 1024 ? stats_chunks(HW) : 0;
+  if (!epilogue_stats_ok(d, pl, G)) return 0;
   return HW / pl.t.BM;
 }
 
@@ -151,7 +170,9 @@ int f16x2_gn_parts(const MfConvDesc* d, int G) {
 size_t f16x2_workspace_bytes(const MfConvDesc* d) {
   Plan2 p2;
   if (make_plan2(d, &p2) != MF_OK || !p2.ok || p2.splitk <= 1) return 0;
-  return (size_t)p2.splitk * p2.M * d->Cout * sizeof(float);
+  const size_t slabs = (size_t)p2.splitk * p2.M * d->Cout * sizeof(float);   // (a launch that needs reducer-side statistics still takes this path)
+  const size_t tree = tree_possible(d, p2) ? tree_handoff_bytes(d, p2) : 0;
+  return slabs > tree ? slabs : tree;
 }
 }  // namespace mf
 
@@ -166,7 +187,7 @@ int mf_conv2d_f16x2_ok(const MfConvDesc* d) {
 // slots of the measured-bound array a conv writes per sample (0: it cannot measure -- a tile straddles two samples)
 static int bound_slots2(const MfConvDesc* d, const Plan2& pl, bool with_stats) {
   const int HW = pl.Hout * pl.Wout;
-  if (pl.splitk == 1) return HW % pl.t.BM ? 0 : (HW / pl.t.BM) * (d->Cout / pl.t.BN) * (pl.t.WM * pl.t.WN);
+  if (pl.splitk == 1 || tree_possible(d, pl)) return HW % pl.t.BM ? 0 : (HW / pl.t.BM) * (d->Cout / pl.t.BN) * (pl.t.WM * pl.t.WN);
   if (with_stats) return 0;   // (every convolution followed by a GroupNorm is bounded by the normalisation, not by measurement)
   const long p4 = (long)HW * d->Cout / 4;
   int bx = (int)((p4 + 255) / 256);
@@ -212,9 +233,15 @@ static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of 
   return s < -100 ? -100 : (s > 100 ? 100 : s);
 }
 
+int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {
+  Plan2 pl;
+  if (!d || d->precision != MF_CONV_FP32_F16X2 || make_plan2(d, &pl) != MF_OK || !pl.ok || !tree_possible(d, pl)) return 0;
+  return cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * (pl.splitk - 1);
+}
+
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
-                    float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, double* gn_partial, int G, const MfConvDesc* d,
-                    void* stream) {
+                    float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                    const MfConvDesc* d, void* stream) {
   MF_REQUIRE(d && d->precision == MF_CONV_FP32_F16X2, MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2");
   Plan2 pl;
   int rc = make_plan2(d, &pl);
@@ -242,8 +269,17 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   p.bytes2 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C2);
   p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1));
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
-  if (pl.splitk == 1 && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout / pl.t.BM; }
-  if (pl.splitk > 1) {
+  p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
+  const bool tree = pl.splitk > 1 && tree_possible(d, pl) && (!gn_partial || epilogue_stats_ok(d, pl, G));
+  if ((pl.splitk == 1 || tree) && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout / pl.t.BM; }
+  if (tree) {
+    const size_t need = tree_handoff_bytes(d, pl);
+    MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);
+    MF_REQUIRE(sync, MF_EINVAL, "conv(f16x2): this plan meets its split-K slices inside the launch and needs `sync` "
+                                "(mf_conv2d_f16x2_sync_words(d) zero-initialised words the caller keeps between launches)");
+    p.tree = 1; p.handoff = reinterpret_cast<float*>(workspace); p.sync = sync;
+    if (y_bound && p.bound_slots == 0) p.out_bound = nullptr;
+  } else if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);
     MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);
     p.y = reinterpret_cast<float*>(workspace);
@@ -269,7 +305,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     }
   }
   if (rc) return rc;
-  if (pl.splitk > 1) {
+  if (pl.splitk > 1 && !tree) {
     const int HW = p.HWout;
     ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
     if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ measured bound) in one streaming pass

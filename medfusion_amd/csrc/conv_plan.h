@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "split_f16.h"
+#include "gn_partial.h"
 
 namespace mf {
 
@@ -50,11 +51,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, const floa
   float vmax = 0.f;
   for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < per_sample4; j += stride) {
     const long e = (base + j) * 4;
-    float4 s = *reinterpret_cast<const float4*>(slabs + e);
-    for (int z = 1; z < splitk; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + (long)z * slab + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
+    float4 s = sum_slabs(slabs + e, slab, splitk);
     if (bias) {
       const float4 b = *reinterpret_cast<const float4*>(bias + (e % Cout));
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;

@@ -29,6 +29,33 @@ inline size_t stats_lds_bytes(int Cs) {  // Cs = channels per slice
   return (size_t)(kStatsThreads / lanes_per_row) * Cs * 2 * sizeof(float);
 }
 
+// Sum of the split-K slabs of one float4, in the order the in-launch reduction of the fp16-pair kernel uses (conv_f16x2.h): pairwise,
+// level by level, for a power-of-two count -- so a convolution gives the same bits whether its slices met inside the launch or here --
+// and first to last otherwise.
+__device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sum_slabs(const float* __restrict__ p, long slab, int n) {
+  if (n & (n - 1)) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int z = 1; z < n; ++z) v = add4(v, *reinterpret_cast<const float4*>(p + (long)z * slab));
+    return v;
+  }
+  float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0, l4 = l0, top = l0;
+  for (int z = 0; z < n; ++z) {   // binary-counter carries: level k holds the sum of a finished group of 2^k slabs
+    float4 v = *reinterpret_cast<const float4*>(p + (long)z * slab);
+    if (!(z & 1)) { l0 = v; continue; }
+    v = add4(l0, v);
+    if (!(z & 2)) { l1 = v; continue; }
+    v = add4(l1, v);
+    if (!(z & 4)) { l2 = v; continue; }
+    v = add4(l2, v);
+    if (!(z & 8)) { l3 = v; continue; }
+    v = add4(l3, v);
+    if (!(z & 16)) { l4 = v; continue; }
+    top = add4(l4, v);
+  }
+  return n == 1 ? l0 : n == 2 ? l1 : n == 4 ? l2 : n == 8 ? l3 : n == 16 ? l4 : top;
+}
+
 // grid (chunks, N).  Each block reduces its pixel range of sample n for all channels, then per group.
 // partial[((n*chunks + chunk)*G + g)*2 + {0,1}] = {sum, sumsq} (double).
 // REDUCE: the value is sum_z slabs[z] + bias (split-K reduction) and is also written to y.
@@ -56,12 +83,8 @@ __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* 
       if (REDUCE && bias) bv = *reinterpret_cast<const float4*>(bias + c_off + c4 * 4);
       for (int px = p0 + phase; px < p1; px += rowphases) {
         const long e = nbase + (long)px * C + c_off + c4 * 4;
-        float4 v = *reinterpret_cast<const float4*>(x + e);
+        float4 v = REDUCE ? sum_slabs(x + e, slab, nslabs) : *reinterpret_cast<const float4*>(x + e);
         if (REDUCE) {
-          for (int z = 1; z < nslabs; ++z) {
-            const float4 u = *reinterpret_cast<const float4*>(x + (long)z * slab + e);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-          }
           v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           *reinterpret_cast<float4*>(y + e) = v;
           vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));

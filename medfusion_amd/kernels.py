@@ -57,6 +57,24 @@ class Workspace:
         return buf
 
 
+class SyncWords:
+    """Zero-initialised 32-bit counters the in-launch split-K reduction of mf_conv2d_f16x2 meets through (every launch leaves them zero).
+    One array per (device, stream), like the workspace; grown (re-zeroed) outside graph capture only."""
+
+    _bufs = {}
+
+    @classmethod
+    def get(cls, words: int, device) -> torch.Tensor:
+        key = (device.index, stream(device.index))
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < words:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("medfusion_amd: sync-counter growth during graph capture; run one eager warm-up first")
+            buf = torch.zeros(max(words, 1 << 14), dtype=torch.int32, device=device)
+            cls._bufs[key] = buf
+        return buf
+
+
 def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     """OIHW -> [Cout][KH][KW][Cin] (device, once at load)."""
     _gpu(w_oihw)
@@ -185,13 +203,14 @@ def conv_plan(d: L.MfConvDesc):
 
 def pin_conv_plan(d: L.MfConvDesc):
     """Fix the planner's choice for `d` in its hint fields (later calls with this descriptor skip the table lookup and the cost model) and
-    return what a caller needs per launch: (workspace bytes, slots of the measured-bound array)."""
+    return what a caller needs per launch: (workspace bytes, slots of the measured-bound array, sync words of an in-launch split-K)."""
     lib = L.load()
     if d.precision == 5 and not (d.tile_hint and d.splitk_hint):
         t, k = conv_plan(d)
         if t > 0 and k > 0:
             d.tile_hint, d.splitk_hint = t, k
-    return lib.mf_conv2d_workspace_bytes(C.byref(d)), (lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if d.precision == 5 else 0)
+    return (lib.mf_conv2d_workspace_bytes(C.byref(d)), (lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if d.precision == 5 else 0),
+            (lib.mf_conv2d_f16x2_sync_words(C.byref(d)) if d.precision == 5 else 0))
 
 
 def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
@@ -211,15 +230,17 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     else:
         drop_split(out)
     if pinned is None:
-        pinned = (lib.mf_conv2d_workspace_bytes(C.byref(d)), lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if measure_out and not gn_groups else 0)
-    need, slots = pinned
+        pinned = (lib.mf_conv2d_workspace_bytes(C.byref(d)), lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if measure_out and not gn_groups else 0,
+                  lib.mf_conv2d_f16x2_sync_words(C.byref(d)))
+    need, slots, words = pinned
     if not measure_out or gn_groups:
         slots = 0
     yb = torch.empty((d.N, slots), dtype=torch.float32, device=x1.device) if slots else None
     partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=x1.device) if gn_groups else None
     ws = Workspace.get(need, x1.device) if need else None
+    sync = SyncWords.get(words, x1.device) if words else None
     rc = lib.mf_conv2d_f16x2(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), wmax, _ptr(yb), _ptr(ws), need,
-                             _ptr(partial), gn_groups, C.byref(d), stream())
+                             _ptr(sync), _ptr(partial), gn_groups, C.byref(d), stream())
     L.check(rc, "mf_conv2d_f16x2")
     if slots:   # per-(tile, wave) maxima: reduced to the bound of each sample by the first consumer that asks (bound_of), or inside the
         out._mf_slots = yb   # GroupNorm-apply pass that takes this tensor as its residual (without slots a consumer measures on demand)
