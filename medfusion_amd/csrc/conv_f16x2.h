@@ -476,36 +476,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
       }
     }
   }
-  if (p.out_bound) {   // host guarantees HWout % BM == 0: slot ((tile inside the sample), n-tile, wave) of the tile's sample
+  // A tile lies inside one sample (HWout % BM == 0), or -- small images -- holds BM / HWout whole samples, each a whole number of wave rows
+  // (HWout % FM == 0): the host guarantees one of the two whenever it asks for bounds or statistics.
+  const int wm_per_sample = p.HWout >= BM ? WM : p.HWout / FM;            // wave rows (wm) per sample inside this tile
+  const int n_first = m0 / p.HWout;                                        // first sample of the tile
+  if (p.out_bound) {   // slot (tile inside the sample, n-tile, wave inside the sample) of the wave's sample
     vmax = wave_max(vmax);
-    const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
-    if (lane == 0) p.out_bound[(long)n * p.bound_slots + (part * p.tiles_n + tile_n) * NW + wave] = vmax;
+    const int n = n_first + wm / wm_per_sample;
+    const int part = p.HWout >= BM ? (m0 - n_first * p.HWout) / BM : 0;
+    const int wps = wm_per_sample * WN;                                    // waves per sample
+    if (lane == 0 && n < p.N) p.out_bound[(long)n * p.bound_slots + (part * p.tiles_n + tile_n) * wps + (wm % wm_per_sample) * WN + wn] = vmax;
   }
-  if (p.gn_partial) {  // host guarantees splitk == 1, HWout % BM == 0 (tile inside one sample), BN % cpg == 0, cpg % 8 == 0
+  if (p.gn_partial) {  // host guarantees: this workgroup holds final values, BN % cpg == 0, cpg % 8 == 0
     __builtin_amdgcn_s_barrier();   // every wave has finished with its staging region
     float* red = reinterpret_cast<float*>(smem);   // [NW waves][64 lanes][2]
     red[(wave * 64 + lane) * 2] = s1;
     red[(wave * 64 + lane) * 2 + 1] = s2;
     MFC2_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();
-    const int ngl = BN / p.gn_cpg;
-    if (tid < ngl) {
+    const int ngl = BN / p.gn_cpg, spt = WM / wm_per_sample;               // groups in the tile's channel range, samples per tile
+    if (tid < ngl * spt) {
+      const int gl = tid % ngl, si = tid / ngl;
       double s = 0, q = 0;
       const int slots = p.gn_cpg >> 3;
       for (int k = 0; k < slots; ++k) {
-        const int slot8 = tid * slots + k;
+        const int slot8 = gl * slots + k;
         const int wn_ = slot8 / LPR, c8_ = slot8 - wn_ * LPR;
-        for (int wm_ = 0; wm_ < WM; ++wm_)
+        for (int wm_ = si * wm_per_sample; wm_ < (si + 1) * wm_per_sample; ++wm_)
           for (int r = 0; r < RPP; ++r) {
             const float* d = red + ((wm_ * WN + wn_) * 64 + r * LPR + c8_) * 2;
             s += (double)d[0];
             q += (double)d[1];
           }
       }
-      const int n = m0 / p.HWout, part = (m0 - n * p.HWout) / BM;
-      double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + tid)) * 2;
-      o[0] = s;
-      o[1] = q;
+      const int n = n_first + si;
+      const int part = p.HWout >= BM ? (m0 - n_first * p.HWout) / BM : 0;
+      if (n < p.N) {
+        double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + gl)) * 2;
+        o[0] = s;
+        o[1] = q;
+      }
     }
   }
 }

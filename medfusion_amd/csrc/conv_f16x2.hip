@@ -135,18 +135,21 @@ int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
 // stays addressable with 32-bit offsets.  MF_CONV_TREE=0 keeps the reducer (A/B).
 bool tree_possible(const MfConvDesc* d, const Plan2& pl) {
   static const int env = [] { const char* e = getenv("MF_CONV_TREE"); return e ? atoi(e) : 1; }();
-  if (!(env & 1) || !pl.ok || pl.splitk < 2 || (pl.splitk & (pl.splitk - 1))) return false;
+  if (!env || !pl.ok || pl.splitk < 2 || (pl.splitk & (pl.splitk - 1))) return false;
   return 2.0 * (pl.splitk - 1) * pl.t.BM * pl.t.BN * 4.0 < 4294967040.0;
 }
 size_t tree_handoff_bytes(const MfConvDesc* d, const Plan2& pl) {
   return (size_t)cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * 2u * (pl.splitk - 1) * pl.t.BM * pl.t.BN * sizeof(float);
 }
 // can the epilogue of the (last) workgroup of a tile emit the GroupNorm records: the tile lies inside one sample and holds whole groups
+// a tile lies inside one sample, or holds whole samples each made of whole wave rows (small images): the epilogue can tell samples apart
+bool tile_sample_aligned(const Plan2& pl) {
+  const int HW = pl.Hout * pl.Wout, FM = pl.t.BM / pl.t.WM;
+  return HW % pl.t.BM == 0 || (pl.t.BM % HW == 0 && HW % FM == 0);
+}
 bool epilogue_stats_ok(const MfConvDesc* d, const Plan2& pl, int G) {
-  const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
-  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); return e ? atoi(e) : 1; }();
-  if (pl.splitk > 1 && (env & 2)) return false;
-  return !(HW % pl.t.BM || pl.t.BN % cpg || cpg % 8);
+  const int cpg = d->Cout / G;
+  return tile_sample_aligned(pl) && pl.t.BN % cpg == 0 && cpg % 8 == 0;
 }
 
 // partial GroupNorm records the f16x2 convolution (or its split-K reducer) emits; 0: it cannot
@@ -156,7 +159,7 @@ int gn_parts2(const MfConvDesc* d, const Plan2& pl, int G) {
   if (pl.splitk > 1 && !(tree_possible(d, pl) && epilogue_stats_ok(d, pl, G)))
     return stats_lds_bytes(d->Cout / stats_slices(d->N, HW, d->Cout, G)) <= 64 * 1024 ? stats_chunks(HW) : 0;
   if (!epilogue_stats_ok(d, pl, G)) return 0;
-  return HW / pl.t.BM;
+  return HW >= pl.t.BM ? HW / pl.t.BM : 1;
 }
 
 
@@ -187,7 +190,11 @@ int mf_conv2d_f16x2_ok(const MfConvDesc* d) {
 // slots of the measured-bound array a conv writes per sample (0: it cannot measure -- a tile straddles two samples)
 static int bound_slots2(const MfConvDesc* d, const Plan2& pl, bool with_stats) {
   const int HW = pl.Hout * pl.Wout;
-  if (pl.splitk == 1 || tree_possible(d, pl)) return HW % pl.t.BM ? 0 : (HW / pl.t.BM) * (d->Cout / pl.t.BN) * (pl.t.WM * pl.t.WN);
+  if (pl.splitk == 1 || tree_possible(d, pl)) {   // per (tile inside the sample, n-tile, wave inside the sample)
+    if (!tile_sample_aligned(pl)) return 0;
+    const int nw = pl.t.WM * pl.t.WN;
+    return HW >= pl.t.BM ? (HW / pl.t.BM) * (d->Cout / pl.t.BN) * nw : (d->Cout / pl.t.BN) * (nw * HW / pl.t.BM);
+  }
   if (with_stats) return 0;   // (every convolution followed by a GroupNorm is bounded by the normalisation, not by measurement)
   const long p4 = (long)HW * d->Cout / 4;
   int bx = (int)((p4 + 255) / 256);
@@ -271,7 +278,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
   const bool tree = pl.splitk > 1 && tree_possible(d, pl) && (!gn_partial || epilogue_stats_ok(d, pl, G));
-  if ((pl.splitk == 1 || tree) && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout / pl.t.BM; }
+  if ((pl.splitk == 1 || tree) && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout >= pl.t.BM ? p.HWout / pl.t.BM : 1; }
   if (tree) {
     const size_t need = tree_handoff_bytes(d, pl);
     MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);

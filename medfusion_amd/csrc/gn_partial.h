@@ -33,27 +33,24 @@ inline size_t stats_lds_bytes(int Cs) {  // Cs = channels per slice
 // level by level, for a power-of-two count -- so a convolution gives the same bits whether its slices met inside the launch or here --
 // and first to last otherwise.
 __device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+template <int N_>
+__device__ __forceinline__ float4 sum_slabs_tree(const float* __restrict__ p, long slab) {
+  if constexpr (N_ == 1) return *reinterpret_cast<const float4*>(p);
+  else return add4(sum_slabs_tree<N_ / 2>(p, slab), sum_slabs_tree<N_ / 2>(p + (long)(N_ / 2) * slab, slab));
+}
 __device__ __forceinline__ float4 sum_slabs(const float* __restrict__ p, long slab, int n) {
-  if (n & (n - 1)) {
-    float4 v = *reinterpret_cast<const float4*>(p);
-    for (int z = 1; z < n; ++z) v = add4(v, *reinterpret_cast<const float4*>(p + (long)z * slab));
-    return v;
+  switch (n) {
+    case 1: return sum_slabs_tree<1>(p, slab);
+    case 2: return sum_slabs_tree<2>(p, slab);
+    case 4: return sum_slabs_tree<4>(p, slab);
+    case 8: return sum_slabs_tree<8>(p, slab);
+    case 16: return sum_slabs_tree<16>(p, slab);
+    case 32: return sum_slabs_tree<32>(p, slab);
+    default: break;
   }
-  float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, l2 = l0, l3 = l0, l4 = l0, top = l0;
-  for (int z = 0; z < n; ++z) {   // binary-counter carries: level k holds the sum of a finished group of 2^k slabs
-    float4 v = *reinterpret_cast<const float4*>(p + (long)z * slab);
-    if (!(z & 1)) { l0 = v; continue; }
-    v = add4(l0, v);
-    if (!(z & 2)) { l1 = v; continue; }
-    v = add4(l1, v);
-    if (!(z & 4)) { l2 = v; continue; }
-    v = add4(l2, v);
-    if (!(z & 8)) { l3 = v; continue; }
-    v = add4(l3, v);
-    if (!(z & 16)) { l4 = v; continue; }
-    top = add4(l4, v);
-  }
-  return n == 1 ? l0 : n == 2 ? l1 : n == 4 ? l2 : n == 8 ? l3 : n == 16 ? l4 : top;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int z = 1; z < n; ++z) v = add4(v, *reinterpret_cast<const float4*>(p + (long)z * slab));
+  return v;
 }
 
 // grid (chunks, N).  Each block reduces its pixel range of sample n for all channels, then per group.
