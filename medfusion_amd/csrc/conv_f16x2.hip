@@ -54,7 +54,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   // by scripts/conv_sweep.py --emit-table on MI355X), else a cost model fitted to the same sweeps (microseconds):
   //   launch + prologue + epilogue  ~7
   //   main loop                     ceil(workgroups / resident slots) * iterations * t_it(tile)
-  //   split-K reducer               4 + (sk + 1) * output bytes / 3.5 TB/s
+  //   split-K                       3 per level of the in-launch tree (power-of-two splits), else reducer 4 + (sk + 1) * output bytes / 3.5 TB/s
   const long out_bytes = (long)pl->M * d->Cout * 4;
   auto valid = [&](const Tile2& k) { return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0); };
   auto sk_ok = [&](int sk) { return sk >= 1 && sk <= pl->cgroups; };
@@ -97,7 +97,8 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
         if (k.BM * k.BN <= 128 * 64) t_it = (wgs > 256 ? 0.80 : 0.43);      // half-size tiles: two per CU when the grid is that large
         else if (percu == 2) t_it = (wgs > 256 ? 1.40 : 0.75);              // 4-wave 128 x 128
         double cost = 7.0 + waves * (its + 3.0) * t_it;
-        if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;
+        if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += 3.0 * lv; }   // the slices meet inside the launch
+        else if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;                          // slabs + reducer pass
         if (cost < best) { best = cost; bc = &k; bsk = s; }
       }
     }
