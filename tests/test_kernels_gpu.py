@@ -693,3 +693,31 @@ def test_conv_f16x2_two_source_1x1_at_published_sizes(dev, shape):
         if first is None:
             first = y.clone()
         assert torch.equal(y, first), (shape, rep)
+
+
+@pytest.mark.parametrize("case", [(16, 16, 16, 512, 0, 512, 3, 53, 2), (16, 16, 16, 512, 0, 512, 3, 54, 2), (16, 16, 16, 512, 0, 512, 3, 36, 2),
+                                  (16, 16, 16, 512, 0, 512, 3, 33, 2), (16, 16, 16, 1024, 0, 512, 3, 51, 4), (16, 8, 8, 1536, 0, 512, 3, 53, 8),
+                                  (16, 8, 8, 1024, 1024, 1024, 3, 31, 8), (16, 32, 32, 256, 256, 256, 3, 32, 2), (16, 16, 16, 512, 512, 512, 1, 53, 2)])
+def test_conv_f16x2_split_k_meets_inside_the_launch(dev, case):
+    """the in-launch split-K reduction under the condition that exposes a stale or lost hand-off: launches ALTERNATE between different
+    inputs (a tile read too early, through a stale cache line, or not added at all shows up against the un-split launch of the same input),
+    and equal inputs give equal bits.  Shapes and (tile, split) pairs of the cfg2 batch."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, tile, sk = case
+    g = torch.Generator().manual_seed(5)
+    pad = 1 if k == 3 else 0
+    wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
+    b = torch.randn((co,), generator=g).to(dev)
+    wh = K.split_weight_f16x2(wt)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=tile, splitk_hint=sk, precision=5)
+    d1 = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=tile, splitk_hint=1, precision=5)
+    xs = [(torch.randn((n, h, w, c1), generator=g).to(dev) * (1 + 3 * i), torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None) for i in range(2)]
+    refs = [K.conv2d_f16x2(x, wh, b, d1, x2=x2).clone() for x, x2 in xs]
+    firsts = [None, None]
+    for rep in range(16):
+        i = (rep + rep // 3) % 2
+        y = K.conv2d_f16x2(xs[i][0], wh, b, d, x2=xs[i][1], measure_out=bool(rep % 2))
+        assert float((y - refs[i]).abs().max() / refs[i].abs().max()) < 1e-5, (case, rep)
+        if firsts[i] is None:
+            firsts[i] = y.clone()
+        assert torch.equal(y, firsts[i]), (case, rep)
