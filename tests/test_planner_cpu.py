@@ -28,9 +28,17 @@ def test_split_k_workspace_and_gn_parts_are_consistent(prec):
         ws = lib.mf_conv2d_workspace_bytes(C.byref(d))
         n, h, w, _, _, co = shape
         out_bytes = n * h * w * co * 4
-        assert ws % out_bytes == 0                      # 0 (no split-K) or splitk slabs of the output size
-        sk = ws // out_bytes
-        assert sk == 0 or 2 <= sk <= 16
+        tile, sk = K.conv_plan(d)
+        assert tile > 0 and 1 <= sk <= 16
+        if sk == 1:
+            assert ws == 0
+        elif prec == 5 and sk & (sk - 1) == 0:           # the slices meet inside the launch: two hand-off slots per pair and level, a counter per pair
+            assert ws >= max(sk, 2 * (sk - 1)) * out_bytes and ws % out_bytes == 0
+            words = lib.mf_conv2d_f16x2_sync_words(C.byref(d))
+            assert words > 0 and words % (sk - 1) == 0    # tiles x (sk - 1)
+        else:                                             # slabs of the output size + reducer pass
+            assert ws == sk * out_bytes
+            assert prec != 5 or lib.mf_conv2d_f16x2_sync_words(C.byref(d)) == 0
         G = 32 if co >= 256 else 8                      # UNet levels: 32 groups; VAE levels: 8 (the fp16-pair epilogue needs >= 8 channels per group)
         parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
         assert 0 < parts <= max(16, h * w // 64)       # every large conv of the path can emit GroupNorm partials
@@ -38,7 +46,7 @@ def test_split_k_workspace_and_gn_parts_are_consistent(prec):
             assert lib.mf_conv2d_f16x2_ok(C.byref(d)) == 1
         if prec in (3, 5):                               # split modes: one accumulation chain <= 96 chunks of 32
             chunks = 9 * (shape[3] + shape[4]) // 32
-            assert chunks / max(sk, 1) <= 96
+            assert chunks / sk <= 96
 
 
 def test_subpixel_form_availability():
