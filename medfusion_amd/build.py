@@ -22,7 +22,8 @@ HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_pla
 # anywhere else in the instruction stream.  Built without packed fp32 the same sources are exact and bit-reproducible
 # (scripts/tree_repro.py, tests/test_kernels_gpu.py::test_conv_f16x2_two_source_1x1_at_published_sizes).  The feature is turned off for
 # that translation unit only: the other kernels use packed fp32 (the fp32 edge convolutions are 40 % faster with it) and are pinned bit for bit
-# by their own tests.
+# by their own tests.  (A per-kernel `__attribute__((target("no-packed-fp32-ops")))` does the same for the arithmetic but cost 10 % of the
+# step -- 30.2 vs 33.8 images/s in one session -- because helpers without the attribute are no longer inlined into the kernel.)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall",
           "-Wno-unused-function"]
 EXTRA_CFLAGS = {"conv_f16x2.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
