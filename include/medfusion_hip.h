@@ -108,8 +108,9 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
  *   `workspace` with write-through stores, a counter per pair in `sync` tells the workgroup that arrives second to add its partner's tile
  *   (a + b does not depend on who adds: deterministic), the last one runs the ordinary epilogue -- no reducer launch.  `sync`:
  *   mf_conv2d_f16x2_sync_words(d) 32-bit words, zero before the FIRST launch and left zero by every launch (caller keeps them; one array
- *   per stream is enough).  Other splits (or GroupNorm statistics the epilogue cannot emit) take the slab + reducer pass, the reducer
- *   emitting y, the statistics and y_bound.
+ *   per stream is enough).  Other splits (or GroupNorm statistics the epilogue cannot emit; or MF_CONV_TREE=0 in the environment, read once)
+ *   take the slab + reducer pass, the reducer emitting y, the statistics and y_bound; it sums the slabs in the same pairwise order, so the
+ *   two paths give the same bits.
  * mf_conv2d_plan_query: the tile id and split-K factor the planner picks for `d` (any precision; 0, 0 = not on the implicit-GEMM path). */
 int mf_conv2d_f16x2_ok(const MfConvDesc* d);
 int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d);
