@@ -119,3 +119,18 @@ def test_planner_properties_over_many_descriptors():
             parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
             assert parts >= 0 and (ig or parts == 0)
     assert seen_split > 20   # the sweep does exercise that branch
+
+
+def test_pinned_plan_equals_the_planners_choice():
+    """kernels.pin_conv_plan fixes (tile, split-K) in the descriptor's hint fields so that the per-launch planning of the sampling loop is a
+    field read: the pinned descriptor must plan exactly like the free one, and the sizes returned once must equal fresh queries"""
+    lib = L.load()
+    for shape in [(16, 32, 32, 256, 0, 256), (16, 16, 16, 512, 512, 512), (16, 8, 8, 1024, 1024, 1024), (8, 64, 64, 256, 0, 256), (16, 16, 16, 256, 0, 512)]:
+        free = _d(*shape, prec=5)
+        want = K.conv_plan(free)
+        d = _d(*shape, prec=5)
+        need, slots, words = K.pin_conv_plan(d)
+        assert (d.tile_hint, d.splitk_hint) == want and K.conv_plan(d) == want
+        assert need == lib.mf_conv2d_workspace_bytes(C.byref(free)) and slots == lib.mf_conv2d_f16x2_bound_slots(C.byref(free))
+        assert words == lib.mf_conv2d_f16x2_sync_words(C.byref(free))
+        assert lib.mf_conv2d_gn_parts(C.byref(d), 32) == lib.mf_conv2d_gn_parts(C.byref(free), 32)
