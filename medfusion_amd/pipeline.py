@@ -171,7 +171,7 @@ class DiffusionPipeline(nn.Module):
         if use_graph is None:
             # Replaying the iteration as a captured hipGraph removes the host's 2.0 ms of launch work per iteration but dispatches every
             # kernel node ~1 us later than a stream-ordered launch (profiles/r02_host_enqueue_time.txt, ms per 150 iterations, graph vs
-            # eager: B=1 at 8x8 254 vs 298, B=4 at 32x32 337 vs 321, B=8 392 vs 371, B=16 538 vs 512): worth it only while the host
+            # eager: B=1 at 8x8 227 vs 301, B=4 at 32x32 275 vs 272, B=8 359 vs 341, B=16 521 vs 493): worth it only while the host
             # is the bottleneck.
             from .noise import PhiloxDeviceNoise
             rows = x_t.shape[0] * (2 if (condition is not None and guidance_scale != 1.0) else 1)
