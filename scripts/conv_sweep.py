@@ -154,6 +154,7 @@ def main():
                     d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))
             res.sort()
+            t_auto = min(t_auto, time_conv(x1, x2, wt, b, d0, args.reps))   # (the first timing of a shape runs on clocks that are still ramping: long VAE rows lose 20 %)
         best = res[0] if res else (t_auto, 0, 0)
         if res and best[0] < 0.985 * t_auto:   # keep the planner's own choice unless the sweep beats it by more than the noise
             table.append((n, h, w_, c1 + c2, co, k, st, ups, best[1], best[2]))
