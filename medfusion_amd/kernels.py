@@ -74,6 +74,15 @@ class SyncWords:
             cls._bufs[key] = buf
         return buf
 
+    @classmethod
+    def reset(cls, device) -> None:
+        """Zero the counters of the current stream again (one memset): a launch that died half-way -- a device fault, an interrupted
+        process -- would otherwise leave a pair's counter at 1 and the next launch would take a stale tile.  Called once per sampling loop /
+        VAE pass, never per launch."""
+        buf = cls._bufs.get((device.index, stream(device.index)))
+        if buf is not None and not torch.cuda.is_current_stream_capturing():
+            buf.zero_()
+
 
 def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     """OIHW -> [Cout][KH][KW][Cin] (device, once at load)."""

@@ -155,6 +155,7 @@ class DiffusionPipeline(nn.Module):
             return self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs)
 
     def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs):
+        K.SyncWords.reset(x_t.device)   # (the split-K counters of the convolutions: zero by invariant, re-zeroed once per loop for robustness)
         if "eta" in kwargs:
             raise TypeError("forward() got an unexpected keyword argument 'eta'")
         guidance_scale = kwargs.pop("guidance_scale", 1.0)

@@ -56,6 +56,7 @@ class VAE(nn.Module):
         """x [B,3,H,W] NCHW -> z [B,emb,H/8,W/8] NCHW (stochastic: one N(0,1) draw of z's shape)."""
         if not x.is_cuda:
             raise RuntimeError("medfusion_amd.VAE runs on a ROCm device only (no CPU fallback)")
+        K.SyncWords.reset(x.device)
         h = self.inc(x.contiguous(), None, in_layout=L.LAYOUT_NCHW)
         for enc in self.encoders:
             h = enc(h)
@@ -73,6 +74,7 @@ class VAE(nn.Module):
         """z [B,emb,h,w] NCHW -> x [B,3,8h,8w] NCHW."""
         if not z.is_cuda:
             raise RuntimeError("medfusion_amd.VAE runs on a ROCm device only (no CPU fallback)")
+        K.SyncWords.reset(z.device)
         h = self.inc_dec(z.contiguous(), None, in_layout=L.LAYOUT_NCHW)
         for i in range(len(self.decoders), 0, -1):
             h = self.decoders[i - 1](h)
