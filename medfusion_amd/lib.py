@@ -106,7 +106,13 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             from . import build as _build
 
             if _build.needs_build():
-                _build.build(verbose=bool(os.environ.get("MEDFUSION_VERBOSE_BUILD")))
+                import fcntl
+
+                # one builder at a time: the ranks of a multi-GPU launch import the package together (the others find the library fresh)
+                with open(str(LIB_PATH) + ".lock", "w") as lock:
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    if _build.needs_build():
+                        _build.build(verbose=bool(os.environ.get("MEDFUSION_VERBOSE_BUILD")))
         except Exception as e:  # hipcc missing etc. -- fine if a prebuilt .so travelled with the tree
             if not LIB_PATH.exists():
                 raise RuntimeError(f"libmedfusion_hip.so is missing and could not be built: {e}") from e
