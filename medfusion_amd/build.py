@@ -52,6 +52,33 @@ def needs_build() -> bool:
     return _stale(LIB, [CSRC / s for s in SOURCES] + _deps())
 
 
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    # (the HOST pass of a -c compile does not know the device feature named in CFLAGS and says so three times per file)
+    err = "\n".join(line for line in r.stderr.splitlines()
+                    if "is not a recognized feature for this target" not in line and "argument unused during compilation: '--hip-link'" not in line)
+    if err.strip():
+        print(err, file=sys.stderr, flush=True)
+    if r.returncode:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+
+
+def _link(objs, lib: Path, verbose: bool) -> None:
+    """link to a temporary name, load it (every symbol must resolve: a kernel stub the host pass dropped shows up here, not on the GPU
+    box), then rename onto `lib` -- a process that dlopens `lib` meanwhile sees the old file or the new one, never a half-written one"""
+    import ctypes
+    tmp = lib.with_name(f".{lib.name}.{os.getpid()}.tmp")
+    try:
+        _run([hipcc(), *LFLAGS, *[str(o) for o in objs], "-o", str(tmp)], verbose)
+        ctypes.CDLL(str(tmp))
+        os.replace(tmp, lib)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
+
+
 def build(force: bool = False, verbose: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
@@ -62,26 +89,54 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         obj = OBJ / (Path(src).stem + ".o")
         if force or _stale(obj, [CSRC / src] + _deps()):
             jobs.append([cc, *CFLAGS, *EXTRA_CFLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)])
-
-    def run(cmd):
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-        # (the HOST pass of a -c compile does not know the device feature named in CFLAGS and says so three times per file)
-        err = "\n".join(line for line in r.stderr.splitlines() if "is not a recognized feature for this target" not in line)
-        if err.strip():
-            print(err, file=sys.stderr, flush=True)
-        if r.returncode:
-            raise subprocess.CalledProcessError(r.returncode, cmd)
-
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
-        list(ex.map(run, jobs))
-    run([cc, *LFLAGS, *[str(OBJ / (Path(s).stem + ".o")) for s in SOURCES], "-o", str(LIB)])
-    import ctypes
-    ctypes.CDLL(str(LIB))   # every symbol must resolve (a kernel stub the host pass dropped shows up here, not on the GPU box)
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    _link([OBJ / (Path(s).stem + ".o") for s in SOURCES], LIB, verbose)
     return LIB
+
+
+def build_variant(name: str, conv_flags=(), packed_fp32: bool = False, verbose: bool = False) -> Path:
+    """A diagnostic twin of the library (csrc/build/variants/libmedfusion_hip_<name>.so; MEDFUSION_LIB=<path> makes lib.load() take it):
+    conv_f16x2.hip recompiled with `conv_flags` (e.g. -DMFC2_HZ=2) and, with packed_fp32, WITHOUT the -packed-fp32-ops switch-off;
+    every other object is the product build's.  scripts/pk_hunt.py uses it to attribute a wrong result to one spot of the epilogue."""
+    build(verbose=verbose)
+    vdir = OBJ / "variants"
+    vdir.mkdir(exist_ok=True)
+    obj = vdir / f"conv_f16x2_{name}.o"
+    extra = [] if packed_fp32 else EXTRA_CFLAGS["conv_f16x2.hip"]
+    _run([hipcc(), *CFLAGS, *extra, *conv_flags, "-c", str(CSRC / "conv_f16x2.hip"), "-o", str(obj)], verbose)
+    lib = vdir / f"libmedfusion_hip_{name}.so"
+    _link([obj if s == "conv_f16x2.hip" else OBJ / (Path(s).stem + ".o") for s in SOURCES], lib, verbose)
+    return lib
+
+
+# gfx950 erratum (scripts/pk_repro_min.hip, profiles/r03_pk_repro.txt): a packed fp32 VALU instruction whose LOW result takes the HIGH half of
+# src1 (op_sel's second bit set: "v_pk_mul_f32 vD, vA, vB op_sel:[0,1]") reads that operand as 0.0 in lanes 48..63 now and then, when the
+# other wave of the SIMD issues matrix instructions while LDS reads return.  hipcc 7.2 forms that operand selection by itself when it packs
+# scalar fp32 code, and pads nothing.  No translation unit of the library may contain it.
+_PK_SRC1_HIGH = __import__("re").compile(r"^\s*v_pk_(?:mul|add|fma)_f32\b.*\bop_sel:\[[01],1")
+
+
+def lint_isa(verbose: bool = False):
+    """Compile every translation unit to device assembly with its own flags (cached under csrc/build/lint) and return the packed fp32
+    instructions that select the high half of src1 for their low result, as (source, line text) pairs -- must be empty."""
+    lint = OBJ / "lint"
+    lint.mkdir(parents=True, exist_ok=True)
+    cc = hipcc()
+
+    def one(src):
+        out = lint / (Path(src).stem + ".s")
+        if _stale(out, [CSRC / src] + _deps() + [Path(__file__)]):
+            _run([cc, *CFLAGS, *EXTRA_CFLAGS.get(src, []), "--cuda-device-only", "-S", str(CSRC / src), "-o", str(out)], verbose)
+        return [(src, ln.strip()) for ln in out.read_text().splitlines() if _PK_SRC1_HIGH.match(ln)]
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        return [hit for hits in ex.map(one, SOURCES) for hit in hits]
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    if "--lint" in sys.argv:
+        bad = lint_isa()
+        print("ISA lint:", "clean" if not bad else bad)

@@ -34,8 +34,8 @@ _PLACEHOLDER_PREFIXES = ("medical_diffusion", "pytorch_lightning", "lightning", 
 # everything else must come from here (a checkpoint is data: no other global may be resolved, so unpickling cannot run foreign code)
 _ALLOWED = {
     "collections": {"OrderedDict", "defaultdict"},
-    "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "complex", "slice", "range", "object",
-                 "getattr", "bytearray"},
+    # (no `getattr`, no `object`: getattr(object, "__subclasses__")() reaches every class of the interpreter)
+    "builtins": {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "complex", "slice", "range", "bytearray"},
     "pathlib": {"Path", "PosixPath", "PurePosixPath", "WindowsPath", "PureWindowsPath"},
     "numpy": {"ndarray", "dtype"},
     "numpy.core.multiarray": {"_reconstruct", "scalar"},
@@ -44,7 +44,9 @@ _ALLOWED = {
               "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "Tensor", "float32", "float64", "float16", "bfloat16", "int64",
               "int32", "int16", "int8", "uint8", "bool"},
     "torch._utils": {"_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_tensor", "_rebuild_parameter_with_state"},
-    "torch.storage": {"UntypedStorage", "TypedStorage", "_load_from_bytes"},
+    # (no `_load_from_bytes`: it is torch.load(BytesIO(b), weights_only=False), an unrestricted nested unpickle; only the legacy
+    # non-zip format needs it)
+    "torch.storage": {"UntypedStorage", "TypedStorage"},
     "torch.nn.parameter": {"Parameter"},
     "torch.serialization": {"_get_layout"},
 }

@@ -25,6 +25,10 @@
 #include "common.h"
 #include "split_f16.h"
 
+#ifndef MFC2_HZ
+#define MFC2_HZ 0   // diagnostic hooks (below): 0 in the product build
+#endif
+
 namespace mfc2 {
 using namespace mf;
 
@@ -61,6 +65,9 @@ struct ConvP2 {
   int tree;
   float* handoff;       // [tiles][2 (splitk - 1) slots][BM x BN floats]
   unsigned* sync;       // [tiles][splitk - 1] counters, zero between launches (the second arriver of a pair resets its counter)
+#if MFC2_HZ & 256
+  float* dbg;           // diagnostic builds: [tiles][waves][TM][TN][16][64] the accumulators of the surviving workgroup right behind the tree
+#endif
 };
 
 __device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; block b runs on XCD b % 8
@@ -69,6 +76,20 @@ __device__ __forceinline__ int xcd_remap2(int bid, int total) {  // bijective; b
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + within;
 }
+
+// Diagnostic builds (scripts/pk_hunt.py): -DMFC2_HZ=<bit mask> pads single spots of the epilogue with wait states / full waits so that a
+// sporadic wrong result can be attributed to ONE producer -> consumer pair.  0 (the product build): every hook expands to nothing.
+#ifndef MFC2_HZ
+#define MFC2_HZ 0
+#endif
+#define MFC2_HZ_ON(BIT) ((MFC2_HZ >> (BIT)) & 1)
+#ifndef MFC2_HZ_PAD
+#define MFC2_HZ_PAD 7
+#endif
+
+// un-packed fp32 arithmetic the compiler cannot pair into v_pk_*_f32 (hooks 5, 6)
+__device__ __forceinline__ float hz_add(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hz_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 #define MFC2_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -240,6 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     const int e2_ = (p.bound2 && p.C2 > 0) ? scale_exp_of(p.bound2[pn_]) : 0;
 #define MFC2_SOURCE_SWITCH()                                                                                            \
   if (__builtin_expect(it == it_sw, 0)) {                                                                               \
+    if constexpr (MFC2_HZ_ON(0)) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                     \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                    \
       MFC2_PIXEL_EXPS(i)                                                                                                \
       const float f_ = exp2i(e1_) * exp2i(-e2_);                                                                        \
@@ -359,6 +381,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   // All DMA has landed (the last iterations wait vmcnt(0)); the stages are dead once every wave has left the loop.
   MFC2_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
+  if constexpr (MFC2_HZ_ON(0)) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   if (p.tree) {   // ---- split-K met inside the launch (see ConvP2)
     // the accumulators become the values of this K slice, (main + cross / 2048) x 2^(operand scales); `accx` is cleared so that the
     // epilogue below, which forms the same expression for the other launches, reproduces them (f_out = 1 there)
@@ -380,6 +403,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     const unsigned lane_off = (unsigned)((wave * TM * TN * 4) * 64 + lane) * 16u;
     int lbase = 0;
     for (int span = 1; span < p.splitk; span <<= 1) {
+      if constexpr (MFC2_HZ_ON(4)) asm volatile("s_nop 15" ::: "memory");
       const int lv = __builtin_ctz(span);
       const int side = (kz >> lv) & 1, pair = kz >> (lv + 1);
       const unsigned mine = (unsigned)(2 * (lbase + pair) + side) * (unsigned)SLOT * 4u, theirs = (unsigned)(2 * (lbase + pair) + (side ^ 1)) * (unsigned)SLOT * 4u;
@@ -395,16 +419,50 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
             __builtin_amdgcn_raw_buffer_store_b128(v, rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), mine, 0x10);   // sc1: agent scope, write-through
           }
       MFC2_WAIT_VM(0);
+      if constexpr (MFC2_HZ_ON(4)) asm volatile("s_nop 15" ::: "memory");
       __syncthreads();
       if (tid == 0) {
+        // Publication.  The payload went out as 16-byte sc1 (write-through, agent scope) stores that every wave has waited for
+        // (vmcnt(0) + barrier above), the partner reads it with sc1 loads behind the counter: the {sc1 stores, sc1 loads} hand-off of
+        // MI355X_MICROARCH.md "Workgroup dispatch ... visibility".  tree == 2 adds the memory model's own fences around the counter
+        // (release = buffer_wbl2 sc1 + vmcnt(0) before the bump, acquire = buffer_inv sc1 after the second arriver's bump; one lane,
+        // then the barrier below) -- the form that does not lean on cache-policy bits; MF_CONV_TREE selects (conv_f16x2.hip).
+        if (p.tree == 2) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          MFC2_WAIT_VM(0);   // (restated where the compiler cannot drop it: ROCm 7.2 elides the wait behind buffer_wbl2 after an explicit vmcnt(0))
+        }
         const unsigned old = __hip_atomic_fetch_add(cnt + lbase + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old) __hip_atomic_store(cnt + lbase + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // second: nobody touches it again in this launch
+        if (p.tree == 2 && old) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         *flag = old;
       }
       __syncthreads();
       const unsigned second = *flag;
       __syncthreads();   // (the flag word is rewritten at the next level)
       if (!second) return;            // the partner finishes this tile
+      if constexpr (MFC2_HZ_ON(3)) {   // every load landed before the first add
+        u32x4 pv[TM * TN * 4];
+#pragma unroll
+        for (int u = 0; u < TM * TN * 4; ++u) pv[u] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(u * 1024), theirs, 0x10);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" ::: "memory");
+#if MFC2_HZ & 256
+        if (p.dbg) {   // [1]: this workgroup's own values, [2]: what it loaded from its partner (layout of [0], the sum dumped behind the tree)
+          const long plane = (long)p.tiles_m * p.tiles_n * NW * (TM * TN * 16 * 64);
+          float* o = p.dbg + ((long)tile * NW + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+          for (int u = 0; u < TM * TN * 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              __builtin_nontemporal_store(accm[u / (4 * TN)][(u / 4) % TN][4 * (u % 4) + e], o + plane + (u * 4 + e) * 64);
+              __builtin_nontemporal_store(__uint_as_float(pv[u][e]), o + 2 * plane + (u * 4 + e) * 64);
+            }
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < TM * TN * 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accm[u / (4 * TN)][(u / 4) % TN][4 * (u % 4) + e] += __uint_as_float(pv[u][e]);
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -413,10 +471,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
           for (int q = 0; q < 4; ++q) {
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), theirs, 0x10);   // sc1: past this XCD's L2
 #pragma unroll
-            for (int e = 0; e < 4; ++e) accm[i][j][4 * q + e] += __uint_as_float(v[e]);
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (MFC2_HZ_ON(5)) accm[i][j][4 * q + e] = hz_add(accm[i][j][4 * q + e], __uint_as_float(v[e]));
+              else accm[i][j][4 * q + e] += __uint_as_float(v[e]);
+            }
           }
+      }
       lbase += p.splitk >> (lv + 1);
     }
+#if MFC2_HZ & 256
+    if (p.dbg) {
+      float* o = p.dbg + ((long)tile * NW + wave) * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(accm[i][j][r], o + ((i * TN + j) * 16 + r) * 64);
+    }
+#endif
   }
   const bool last_slice = p.splitk == 1 || p.tree;   // this workgroup holds final values: bias, statistics, bounds
   constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [32 pixels][FN couts] fp32 (+16 B: conflict-free b128 writes)
@@ -442,14 +515,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out;
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (MFC2_HZ_ON(6)) v[e] = hz_mul(hz_add(accm[i][j][4 * q + e], hz_mul(accx[i][j][4 * q + e], kLoInv)), f_out);
+          else v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out;
+        }
         *reinterpret_cast<f32x4*>(stg + (lane & 31) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
+        if constexpr (MFC2_HZ_ON(7)) asm volatile("s_nop 0" ::: "memory");
+        if constexpr (MFC2_HZ_ON(1)) asm volatile("s_nop %1" : "+v"(v) : "n"(MFC2_HZ_PAD) : "memory");   // the data registers stay untouched for PAD + 1 states
       }
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + rr;
       f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32);
       f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32 + 16);
+      if constexpr (MFC2_HZ_ON(2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(v0), "+v"(v1)::"memory");
       v0 += b0;
       v1 += b1;
       const int m = m0 + wm * FM + i * 32 + row;

@@ -134,9 +134,14 @@ int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
 
 // split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
 // stays addressable with 32-bit offsets.  MF_CONV_TREE=0 keeps the reducer (A/B).
+// MF_CONV_TREE: 0 = slabs + reducer pass, 1 = in-launch hand-off through sc1 stores / sc1 loads, 2 = the same with release / acquire
+// fences around the pair counter
+int tree_mode() {
+  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); const int v = e ? atoi(e) : 1; return v < 0 || v > 2 ? 1 : v; }();
+  return env;
+}
 bool tree_possible(const MfConvDesc* d, const Plan2& pl) {
-  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); return e ? atoi(e) : 1; }();
-  if (!env || !pl.ok || pl.splitk < 2 || (pl.splitk & (pl.splitk - 1))) return false;
+  if (!tree_mode() || !pl.ok || pl.splitk < 2 || (pl.splitk & (pl.splitk - 1))) return false;
   return 2.0 * (pl.splitk - 1) * pl.t.BM * pl.t.BN * 4.0 < 4294967040.0;
 }
 size_t tree_handoff_bytes(const MfConvDesc* d, const Plan2& pl) {
@@ -179,6 +184,11 @@ size_t f16x2_workspace_bytes(const MfConvDesc* d) {
   return slabs > tree ? slabs : tree;
 }
 }  // namespace mf
+
+#if MFC2_HZ & 256
+static float* g_conv_dbg = nullptr;
+extern "C" void mf_debug_set_conv_dump(float* p) { g_conv_dbg = p; }   // diagnostic builds only (scripts/pk_dump.py)
+#endif
 
 extern "C" {
 
@@ -278,6 +288,9 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1));
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
+#if MFC2_HZ & 256
+  p.dbg = g_conv_dbg;
+#endif
   const bool tree = pl.splitk > 1 && tree_possible(d, pl) && (!gn_partial || epilogue_stats_ok(d, pl, G));
   if ((pl.splitk == 1 || tree) && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout >= pl.t.BM ? p.HWout / pl.t.BM : 1; }
   if (tree) {
@@ -285,7 +298,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     MF_REQUIRE(workspace && workspace_bytes >= need, MF_EWORKSPACE, "conv(f16x2): workspace %zu < %zu", workspace_bytes, need);
     MF_REQUIRE(sync, MF_EINVAL, "conv(f16x2): this plan meets its split-K slices inside the launch and needs `sync` "
                                 "(mf_conv2d_f16x2_sync_words(d) zero-initialised words the caller keeps between launches)");
-    p.tree = 1; p.handoff = reinterpret_cast<float*>(workspace); p.sync = sync;
+    p.tree = tree_mode(); p.handoff = reinterpret_cast<float*>(workspace); p.sync = sync;
     if (y_bound && p.bound_slots == 0) p.out_bound = nullptr;
   } else if (pl.splitk > 1) {
     const size_t need = (size_t)pl.splitk * pl.M * d->Cout * sizeof(float);

@@ -97,28 +97,35 @@ _lib = None
 
 
 def load(build_if_missing: bool = True) -> C.CDLL:
-    """Load (building first if needed) the HIP library.  Raises RuntimeError -- never falls back."""
+    """Load (building first if needed) the HIP library.  Raises RuntimeError -- never falls back.
+    MEDFUSION_LIB=<path to a .so> loads that file as it is (diagnostic twins of medfusion_amd.build.build_variant)."""
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    path = LIB_PATH
+    override = os.environ.get("MEDFUSION_LIB")
+    if override:
+        path = Path(override)
+        if not path.exists():
+            raise RuntimeError(f"MEDFUSION_LIB={override}: no such file")
+    elif build_if_missing:
         try:
+            import fcntl
+
             from . import build as _build
 
-            if _build.needs_build():
-                import fcntl
-
-                # one builder at a time: the ranks of a multi-GPU launch import the package together (the others find the library fresh)
-                with open(str(LIB_PATH) + ".lock", "w") as lock:
-                    fcntl.flock(lock, fcntl.LOCK_EX)
-                    if _build.needs_build():
-                        _build.build(verbose=bool(os.environ.get("MEDFUSION_VERBOSE_BUILD")))
+            # one builder at a time, and nobody decides "fresh" while another process is between its compile and its rename: the ranks
+            # of a multi-GPU launch import the package together (the lock is taken BEFORE the staleness check)
+            with open(str(LIB_PATH) + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                if _build.needs_build():
+                    _build.build(verbose=bool(os.environ.get("MEDFUSION_VERBOSE_BUILD")))
         except Exception as e:  # hipcc missing etc. -- fine if a prebuilt .so travelled with the tree
             if not LIB_PATH.exists():
                 raise RuntimeError(f"libmedfusion_hip.so is missing and could not be built: {e}") from e
-    if not LIB_PATH.exists():
-        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m medfusion_amd.build` (hipcc, gfx950)")
-    lib = C.CDLL(str(LIB_PATH))
+    if not path.exists():
+        raise RuntimeError(f"{path} not found: build it with `python -m medfusion_amd.build` (hipcc, gfx950)")
+    lib = C.CDLL(str(path))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Stress of mf_conv2d_f16x2 under the conditions that expose a sporadic wrong result (round 2: one output channel of 16 pixels equal to
+the bare bias; a partner's split-K tile not added): thousands of launches that ALTERNATE between different inputs -- a workgroup that
+read its partner's hand-off slot too early, through a stale cache line, or lost a value in its own epilogue shows up against a
+reference launch of the SAME input on ANOTHER tile without split-K (bit-identical by construction: every output element is one fp32
+accumulation chain per K slice, and slices are added pairwise in a fixed order) -- and equal inputs must give equal bits every time.
+
+Nothing is copied to the host per launch: mismatches are counted on the device, one synchronisation per case.  On the first bad launch the
+script maps the wrong elements to (lane, accumulator register) of the epilogue, which is what told the packed-fp32 story apart from a
+hand-off problem.  tests/test_kernels_gpu.py::test_conv_f16x2_stress runs `run_case` with 2000 launches per case.
+
+usage: conv_stress.py [--reps N] [--tiles 33,53] [--tree 0|1|2 (via MF_CONV_TREE in the environment)]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+
+# (N, H, W, C1, C2, Cout, k, tile, splitk): the shapes of the cfg2 batch on the tiles / splits the planner uses for them (0 = its own choice)
+CASES = [
+    (16, 32, 32, 256, 256, 256, 1, 0, 0),      # conv_res of out32 (two-source 1x1): the "bare bias" shape of round 2
+    (16, 32, 32, 256, 256, 256, 1, 33, 1),
+    (16, 16, 16, 512, 512, 512, 1, 53, 2),
+    (16, 32, 32, 256, 256, 256, 3, 32, 2),
+    (16, 32, 32, 256, 0, 256, 3, 52, 1),
+    (16, 32, 32, 256, 0, 256, 3, 53, 2),
+    (16, 16, 16, 512, 0, 512, 3, 53, 1),       # (the two-workgroups-per-CU tiles without split-K)
+    (16, 16, 16, 512, 0, 512, 3, 54, 1),
+    (16, 16, 16, 512, 0, 512, 3, 36, 1),
+    (16, 16, 16, 512, 0, 512, 3, 33, 2),
+    (16, 16, 16, 512, 0, 512, 3, 53, 2),
+    (16, 16, 16, 512, 0, 512, 3, 54, 2),
+    (16, 16, 16, 512, 0, 512, 3, 36, 2),
+    (16, 16, 16, 512, 0, 512, 3, 52, 2),
+    (16, 16, 16, 1024, 0, 512, 3, 51, 4),
+    (16, 8, 8, 1024, 0, 1024, 3, 33, 4),
+    (16, 8, 8, 1024, 0, 1024, 3, 52, 4),
+    (16, 8, 8, 1536, 0, 512, 3, 53, 8),
+    (16, 8, 8, 1024, 1024, 1024, 3, 31, 8),
+    (16, 8, 8, 1024, 1024, 1024, 3, 51, 8),
+]
+
+
+def _describe(y, ref, bias, case, K):
+    """where the first bad launch went wrong: tile-relative position -> (lane, accumulator register) of the epilogue's 32 x 32 blocks, and
+    which other value of the same pixel the wrong one equals (the staging registers of the epilogue hold 8-channel-apart values in turn)"""
+    n, h, w, c1, c2, co, k, tile, sk = case
+    bad = (y != ref).nonzero()
+    lines = [f"    {bad.shape[0]} wrong elements"]
+    seen = {}
+    for idx in bad[:4096].tolist():
+        nn, yy, xx, cc = idx
+        m = (nn * h + yy) * w + xx
+        cb = cc % 32
+        lane = (m % 32) + 32 * ((cb >> 2) & 1)
+        reg = 4 * (cb >> 3) + (cb & 3)
+        seen.setdefault((cc, reg), []).append(lane)
+    for (cc, reg), lanes in list(seen.items())[:6]:
+        lines.append(f"    channel {cc} (accumulator register {reg} of its 32x32 block): lanes {min(lanes)}..{max(lanes)} ({len(lanes)} elements)")
+    # hypotheses about the wrong value v = y - bias against r(c) = ref - bias of the same pixel
+    yb, rb = (y - bias).double(), (ref - bias).double()
+    nn, yy, xx, cc = bad[:4096].unbind(1)
+    v, own = yb[nn, yy, xx, cc], rb[nn, yy, xx, cc]
+    scale = float(rb.abs().max())
+    hyp = {"0 (bare bias)": torch.zeros_like(v)}
+    for dc in (8, -8, 4, -4, 1, -1, 2, -2, 16, -16):
+        ok = (cc + dc >= 0) & (cc + dc < co)
+        other = rb[nn, yy, xx, (cc + dc).clamp(0, co - 1)]
+        hyp[f"r(c{dc:+d})"] = torch.where(ok, other, torch.full_like(other, float("nan")))
+        hyp[f"r(c) + r(c{dc:+d})"] = torch.where(ok, own + other, torch.full_like(other, float("nan")))
+    for name, cand in hyp.items():
+        hits = int(((v - cand).abs() <= 2e-6 * scale).sum())
+        if hits:
+            lines.append(f"    wrong value == {name}: {hits} of {v.numel()} elements")
+    for j in range(min(3, v.numel())):
+        lines.append(f"    e.g. [n {int(nn[j])}, y {int(yy[j])}, x {int(xx[j])}, c {int(cc[j])}]: y - bias = {float(v[j]):.6g}, reference - bias = {float(own[j]):.6g}, "
+                     f"r(c+8) = {float(rb[nn[j], yy[j], xx[j], min(int(cc[j]) + 8, co - 1)]):.6g}, r(c-8) = {float(rb[nn[j], yy[j], xx[j], max(int(cc[j]) - 8, 0)]):.6g}")
+    return "\n".join(lines)
+
+
+def run_case(case, reps, dev, seed=3):
+    """-> (bad launches, description of the first bad one or '')"""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, tile, sk = case
+    g = torch.Generator().manual_seed(seed)
+    pad = 1 if k == 3 else 0
+    wt = (torch.randn((co, k, k, c1 + c2), generator=g) * 0.02).to(dev)
+    b = torch.randn((co,), generator=g).to(dev)
+    wh = K.split_weight_f16x2(wt)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=tile, splitk_hint=sk, precision=5)
+    ptile, psk = K.conv_plan(d)
+    # reference: no split-K, on a tile of another shape
+    rtile = 36 if ptile != 36 else 54
+    dref = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=rtile, splitk_hint=1, precision=5)
+    xs = [(torch.randn((n, h, w, c1), generator=g).to(dev) * (1 + 3 * i), torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None) for i in range(3)]
+    refs = []
+    for x, x2 in xs:
+        r = [K.conv2d_f16x2(x, wh, b, dref, x2=x2).clone() for _ in range(3)]
+        assert torch.equal(r[0], r[1]) and torch.equal(r[0], r[2]), ("reference launch is not reproducible", case)
+        refs.append(r[0])
+    nbad = torch.zeros((), dtype=torch.int64, device=dev)
+    pins = K.pin_conv_plan(d)
+    # an un-split launch equals the reference bit for bit; split-K results differ from the un-split chain by rounding only: those are
+    # held to a tolerance against it AND, bit for bit, to the first result of the same input
+    exact_ref = psk == 1
+    firsts = [None] * 3
+    scale = [float(r.abs().max()) for r in refs]
+    for rep in range(reps):
+        i = (rep * 7 + rep // 5) % 3
+        x, x2 = xs[i]
+        y = K.conv2d_f16x2(x, wh, b, d, x2=x2, measure_out=bool(rep % 2), pinned=pins)
+        if exact_ref:
+            wrong = (y != refs[i]).any()
+        else:
+            if firsts[i] is None:
+                firsts[i] = y.clone()
+            wrong = (y != firsts[i]).any() | (((y - refs[i]).abs().max() / scale[i]) > 1e-5)
+        nbad += wrong.to(torch.int64)
+    total = int(nbad)
+    first_bad = None
+    if total:   # find one bad launch to describe (synchronising per launch now)
+        for rep in range(min(4 * reps, 20000)):
+            i = rep % 3
+            x, x2 = xs[i]
+            y = K.conv2d_f16x2(x, wh, b, d, x2=x2, pinned=pins)
+            want = refs[i] if exact_ref else firsts[i]
+            if not torch.equal(y, want):
+                first_bad = (rep, _describe(y, want, b, case, K))
+                break
+    return total, (ptile, psk), ("" if first_bad is None else f"  first bad launch described (rep {first_bad[0]}):\n{first_bad[1]}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=2000)
+    ap.add_argument("--tiles", type=str, default="")
+    a = ap.parse_args()
+    import os
+    from medfusion_amd import lib as L
+    dev = torch.device("cuda:0")
+    cases = CASES
+    if a.tiles:
+        keep = [int(v) for v in a.tiles.split(",")]
+        cases = [c for c in cases if c[7] in keep]
+    print(f"library: {os.environ.get('MEDFUSION_LIB', L.LIB_PATH)}   MF_CONV_TREE={os.environ.get('MF_CONV_TREE', '1 (default)')}   {a.reps} launches per case", flush=True)
+    total = 0
+    for case in cases:
+        bad, plan, desc = run_case(case, a.reps, dev)
+        print(f"shape {case[:7]} tile {plan[0]} sk {plan[1]}: {bad} bad of {a.reps} alternating launches", flush=True)
+        if desc:
+            print(desc, flush=True)
+        total += bad
+    print("TOTAL bad launches:", total, flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

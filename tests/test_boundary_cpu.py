@@ -100,3 +100,20 @@ def test_state_dict_keys_match_reference_layout():
     assert any(k.startswith("noise_estimator.in_conv.conv.weight") for k in keys)
     assert any(k.startswith("noise_scheduler.alphas_cumprod") for k in keys)
     assert any(k.startswith("ema_model.averaged_model.outc.conv.conv.weight") for k in keys)
+
+
+def test_no_packed_fp32_instruction_takes_the_high_half_of_src1():
+    """gfx950 erratum found in round 3 (scripts/pk_repro_min.hip, profiles/r03_pk_repro.txt): `v_pk_{mul,add,fma}_f32 ... op_sel:[x,1]` -- the LOW
+    result reading the HIGH register of the src1 pair -- gets 0.0 for that operand in lanes 48..63 now and then (MFMAs + returning LDS reads
+    on the other wave of the SIMD).  hipcc forms the selection by itself when it packs scalar fp32 code; it is what made the packed build of
+    the fp16-pair convolution lose split-K partials.  No translation unit of the library may contain one (device assembly of every TU with
+    its own flags, cached under csrc/build/lint), and conv_f16x2.hip contains no packed fp32 arithmetic at all."""
+    from medfusion_amd import build as B
+    assert B._PK_SRC1_HIGH.match("\tv_pk_mul_f32 v[2:3], v[2:3], v[34:35] op_sel:[0,1]")
+    assert B._PK_SRC1_HIGH.match("\tv_pk_fma_f32 v[2:3], v[2:3], v[34:35], v[4:5] op_sel:[0,1,0]")
+    assert B._PK_SRC1_HIGH.match("\tv_pk_add_f32 v[8:9], v[8:9], v[6:7] op_sel:[0,1] op_sel_hi:[1,0]")
+    assert not B._PK_SRC1_HIGH.match("\tv_pk_fma_f32 v[2:3], v[34:35], v[2:3], v[4:5] op_sel:[1,0,0]")   # src0: measured clean
+    assert not B._PK_SRC1_HIGH.match("\tv_pk_mul_f32 v[2:3], v[2:3], v[34:35] op_sel_hi:[1,0]")          # broadcast of the low half: clean
+    assert B.lint_isa() == []
+    asm = (B.OBJ / "lint" / "conv_f16x2.s").read_text()
+    assert "v_pk_mul_f32" not in asm and "v_pk_add_f32" not in asm and "v_pk_fma_f32" not in asm

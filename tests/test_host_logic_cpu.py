@@ -231,6 +231,24 @@ def test_checkpoint_reader_refuses_foreign_globals_and_wrong_architectures(tmp_p
     torch.save({"state_dict": {}, "hyper_parameters": {"f": os.system}}, evil)
     with pytest.raises(pickle.UnpicklingError):
         read_checkpoint(evil)
+    # the escape hatches of an allow-list -- a nested unrestricted unpickle (torch.storage._load_from_bytes is
+    # torch.load(..., weights_only=False)), and getattr / object (getattr(object, "__subclasses__")() reaches every class)
+    import io
+    from medfusion_amd.checkpoint import _RemapUnpickler
+
+    def refuses(module, name):
+        blob = pickle.PROTO + bytes([2]) + pickle.GLOBAL + f"{module}\n{name}\n".encode() + pickle.STOP
+        with pytest.raises(pickle.UnpicklingError, match="allow-list"):
+            _RemapUnpickler(io.BytesIO(blob)).load()
+
+    for module, name in (("torch.storage", "_load_from_bytes"), ("builtins", "getattr"), ("builtins", "object"), ("builtins", "eval"),
+                         ("os", "system"), ("posix", "system"), ("subprocess", "Popen"), ("torch", "load"), ("builtins", "__import__")):
+        refuses(module, name)
+    inner = io.BytesIO()
+    torch.save({"f": os.getcwd}, inner)                      # what the PoC smuggled through _load_from_bytes
+    nested = tmp_path / "nested.ckpt"
+    torch.save({"state_dict": {}, "hyper_parameters": {"payload": inner.getvalue()}}, nested, pickle_protocol=4)
+    assert isinstance(read_checkpoint(nested)["hyper_parameters"]["payload"], bytes)   # bytes stay bytes: nothing unpickles them
     with pytest.raises(RuntimeError, match="missing"):
         load_module_from_checkpoint(M.VAE, CKPT / "tiny_vae" / "last_vae.ckpt", deep_supervision=2)   # a head the checkpoint has no weights for
 

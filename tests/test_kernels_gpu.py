@@ -1,11 +1,16 @@
 """Per-kernel parity on a real MI355X: each C-ABI entry point against a plain torch fp32 CPU reference of the same op
 (floating-point kernels) or the oracle's bit-level spec (scheduler step, Philox)."""
+import os
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
 
 from oracle import restate as R
 from oracle import synth as S
@@ -721,3 +726,54 @@ def test_conv_f16x2_split_k_meets_inside_the_launch(dev, case):
         if firsts[i] is None:
             firsts[i] = y.clone()
         assert torch.equal(y, firsts[i]), (case, rep)
+
+
+def _stress_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("conv_stress", str(ROOT / "scripts" / "conv_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("case", _stress_cases().CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_f16x2_stress(dev, case):
+    """2000 launches per (shape, tile, split-K) of the cfg2 batch, alternating between three inputs, every one compared on the device with an
+    un-split launch on another tile (bit for bit where the plan does not split, else to 1e-5 and bit for bit with the first result of the
+    same input): the test that shows the lost split-K partials of the packed-fp32 build in every launch (profiles/r03_pk_repro.txt) and
+    must stay at zero on the product build.  Includes the two-workgroups-per-CU tiles with and without split-K."""
+    bad, plan, desc = _stress_cases().run_case(case, 2000, dev)
+    assert bad == 0, (case, plan, bad, desc)
+
+
+def _stress_subprocess(env_extra, args):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "conv_stress.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tot = [ln for ln in r.stdout.splitlines() if ln.startswith("TOTAL bad launches:")]
+    assert tot, r.stdout[-2000:]
+    return int(tot[0].split(":")[1]), r.stdout
+
+
+def test_conv_f16x2_stress_with_fences_around_the_pair_counter(dev):
+    """MF_CONV_TREE=2: the same hand-off with the memory model's release / acquire fences around the counter (conv_f16x2.h) -- same bits,
+    zero bad launches (the default form relies on sc1 stores + sc1 loads; profiles/r03_tree_fence_cost.txt has what the fences cost)"""
+    bad, out = _stress_subprocess({"MF_CONV_TREE": "2"}, ["--reps", "600", "--tiles", "53,54,36,31,51"])
+    assert bad == 0, out[-3000:]
+
+
+def test_packed_fp32_twin_of_the_convolution(dev):
+    """The same stress on the twin of the library whose conv_f16x2.hip is compiled WITH packed fp32 (what round 2 switched off).  Its device
+    code contains the operand selection of the gfx950 erratum (the ISA lint flags it); wherever that twin loses split-K partials the lint
+    must have flagged it -- and the product build, which the lint passes, is clean in the test above."""
+    from medfusion_amd import build as B
+    import re
+    twin = B.build_variant("pk", packed_fp32=True)
+    cc = B.hipcc()
+    s_path = B.OBJ / "variants" / "conv_f16x2_pk.s"
+    B._run([cc, *B.CFLAGS, "--cuda-device-only", "-S", str(B.CSRC / "conv_f16x2.hip"), "-o", str(s_path)], False)
+    flagged = sum(1 for ln in s_path.read_text().splitlines() if B._PK_SRC1_HIGH.match(ln))
+    bad, out = _stress_subprocess({"MEDFUSION_LIB": str(twin)}, ["--reps", "300", "--tiles", "53,54,36"])
+    print(f"packed-fp32 twin: {flagged} flagged instructions, {bad} bad launches of the stress")
+    assert bad == 0 or flagged > 0, out[-3000:]
