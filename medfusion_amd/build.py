@@ -16,14 +16,14 @@ OBJ = CSRC / "build"
 LIB = HERE / "libmedfusion_hip.so"
 SOURCES = ["api.hip", "conv.hip", "conv_f16x2.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
 HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_plan.h", "split_f16.h", "conv_plan_table.inc"]
-# -packed-fp32-ops: hipcc 7.2 pairs scalar fp32 arithmetic into v_pk_mul_f32 / v_pk_add_f32; in the epilogue of the fp16-pair convolution the
-# LOW half of such an instruction lost its result in the last 16 lanes of a wave, now and then (one output channel of 16 pixels came out as
-# the bare bias; a partner's split-K tile was not added) -- only on the tiles with <= 2 accumulator blocks per wave, with no difference
-# anywhere else in the instruction stream.  Built without packed fp32 the same sources are exact and bit-reproducible
-# (scripts/tree_repro.py, tests/test_kernels_gpu.py::test_conv_f16x2_two_source_1x1_at_published_sizes).  The feature is turned off for
-# that translation unit only: the other kernels use packed fp32 (the fp32 edge convolutions are 40 % faster with it) and are pinned bit for bit
-# by their own tests.  (A per-kernel `__attribute__((target("no-packed-fp32-ops")))` does the same for the arithmetic but cost 10 % of the
-# step -- 30.2 vs 33.8 images/s in one session -- because helpers without the attribute are no longer inlined into the kernel.)
+# -packed-fp32-ops for conv_f16x2.hip.  gfx950 erratum, root-caused in round 3 (profiles/r03_pk_repro.txt, scripts/pk_repro_min.hip): a packed
+# fp32 instruction whose LOW result takes the HIGH half of src1 ("v_pk_mul_f32 vD, vA, vB op_sel:[0,1]") reads that operand as 0.0 in lanes
+# 48..63 now and then, while the other wave of the SIMD issues MFMAs and LDS reads return -- exactly what a co-resident conv workgroup does.
+# hipcc 7.2 forms that selection by itself when it SLP-packs "(main + cross / 2048) * scale" (72 instructions in the packed build), and a
+# K-slice partial became 0 in 16 lanes of a register (round 2: "a partner's split-K tile was not added", "the bare bias").  The convolution
+# unit is therefore built without packed fp32 at all (32.0 vs 32.1 images/s); the other units keep it (the fp32 edge convolutions are 40 %
+# faster with it) and are scanned for the failing operand selection by lint_isa() below (CPU test).  (A per-kernel
+# `__attribute__((target("no-packed-fp32-ops")))` cost 10 % of the step -- helpers without the attribute are no longer inlined.)
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=off", "-mllvm", "-pragma-unroll-threshold=1000000", "-Wall",
           "-Wno-unused-function"]
 EXTRA_CFLAGS = {"conv_f16x2.hip": ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
