@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 200 /* 0.2.0 */
+#define MF_VERSION 210 /* 0.2.1 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -76,8 +76,13 @@ typedef struct MfConvDesc {
  *   fp32 as wh*xh + (wh*xl + wl*xh)/2048 -- 3 matrix instructions per product instead of 6, dropped term < 2^-22 |a*b|.  Because the
  *   operands need no arithmetic in the kernel, both go HBM -> LDS by LDS-DMA.  Entry point mf_conv2d_f16x2 (operands produced by
  *   mf_split_f16x2 or by the split output of mf_gn_apply_split_f32); every operand tensor carries a per-sample power-of-two scale, so
- *   there is no range limit (mf_gn_apply_split_f32 below has the details). */
-enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4, MF_CONV_FP32_F16X2 = 5 };
+ *   there is no range limit (mf_gn_apply_split_f32 below has the details).
+ * MF_CONV_F16 (opt-in, REDUCED precision; SURVEY 8f row 4, ABI 210): the fp16-pair operands and the LDS-DMA kernel of MF_CONV_FP32_F16X2 with
+ *   ONE product term -- main += wh * xh only, i.e. both operands rounded to fp16 (11 significant bits, the per-sample power-of-two
+ *   scales keep the range), fp32 accumulate.  Same entry point (mf_conv2d_f16x2 with desc.precision = MF_CONV_F16), same operand
+ *   images; a third of the matrix instructions, half of the LDS fragment reads.  Error vs fp64 ~3e-4 per convolution (2^-12 per
+ *   operand); never selected by default, own tolerance in the tests, never the headline. */
+enum { MF_CONV_FP32 = 0, MF_CONV_FP32_SPLIT3_W3 = 3, MF_CONV_BF16 = 4, MF_CONV_FP32_F16X2 = 5, MF_CONV_F16 = 6 };
 
 int mf_pack_conv_weight_f32(const float* w_oihw, float* w_packed, int Cout, int Cin, int KH, int KW, void* stream);
 /* nearest-x2 + 3x3 (conv_blocks.py:123-125) as the transposed-conv-equivalent sub-pixel form: OIHW 3x3 -> [4][Cout][2][2][Cin],

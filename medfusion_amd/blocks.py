@@ -95,11 +95,14 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #   1 fp32 operands split EXACTLY into three bf16 terms (24 bits; weights split once at load), six product terms on the bf16 matrix cores;
 #   0 v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain);
 #   4 opt-in REDUCED precision (operands rounded to bf16, one MFMA term; its own tolerance) -- never a default.
+#   6 opt-in REDUCED precision on the LDS-DMA kernel of 5: the same fp16-pair operands, ONE product term (operands rounded to fp16, 11 bits;
+#     MF_CONV_F16) -- its own tolerance, never a default, never the headline.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "5"))
 
 
 def f16x2_mode() -> bool:
-    return CONV_PRECISION == 5
+    """the activations travel with fp16-pair mirrors (arithmetics 5 and 6 read them)"""
+    return CONV_PRECISION in (5, 6)
 
 
 class Conv(nn.Module):
@@ -114,12 +117,12 @@ class Conv(nn.Module):
         self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
 
-    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out):
-        """MF_CONV_FP32_F16X2, or None when this convolution is not on that kernel"""
-        key = ("f16x2", n, h, w, c1, c2, gn_groups)
+    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5):
+        """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel"""
+        key = ("f16x2", n, h, w, c1, c2, gn_groups, prec)
         ent = self._descs.get(key)
         if ent is None:
-            d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=5)
+            d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=prec)
             ok = K.conv_f16x2_ok(d)
             pinned = K.pin_conv_plan(d) if ok else None     # (tile, split-K) fixed in the descriptor: per-launch planning is a field read
             ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok, pinned)
@@ -155,11 +158,12 @@ class Conv(nn.Module):
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
         prec = CONV_PRECISION
-        if prec not in (0, 1, 4, 5):
-            raise RuntimeError(f"blocks.CONV_PRECISION = {prec}: 0 (fp32 MFMA), 1 (exact bf16 triplets), 4 (opt-in bf16) or 5 (fp16 pairs, default)")
-        if prec == 5:
+        if prec not in (0, 1, 4, 5, 6):
+            raise RuntimeError(f"blocks.CONV_PRECISION = {prec}: 0 (fp32 MFMA), 1 (exact bf16 triplets), 5 (fp16 pairs, default), or the opt-in "
+                               f"reduced precisions 4 (bf16) / 6 (fp16)")
+        if prec in (5, 6):
             if rows is None and in_layout == L.LAYOUT_NHWC and out_layout == L.LAYOUT_NHWC:
-                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out)
+                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec)
                 if r is not None:
                     return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels

@@ -244,11 +244,9 @@ int mf_attention_f32(const float* q, const float* k, const float* v, float* out,
       default: break;
     }
   }
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (first_use_on_device(once))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
   hipLaunchKernelGGL(attention_kernel, dim3((Nq + kWaves * kQPerWave - 1) / (kWaves * kQPerWave), H, B), dim3(256), lds, s, q, k, v, out, H, Nq,
                      Nk, d, scale);
   return check_launch("attention");

@@ -42,6 +42,17 @@ inline int check_launch(const char* what) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute belongs to the (function, device) pair: one flag per device (a process may drive several -- tests, tools), `seen` is a
+// function-local static array of the caller.  True the first time the current device comes by.
+struct DeviceOnce { bool seen[64] = {}; };
+static inline bool first_use_on_device(DeviceOnce& o) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;   // unknown device: set the attribute every time
+  if (o.seen[dev]) return false;
+  o.seen[dev] = true;
+  return true;
+}
+
 // MONAI Swish: x * sigmoid(1.0 * x)  (conv_blocks.py act)
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
 // accurate variant used where parity margins are tight (embedding MLPs): expf, IEEE divide

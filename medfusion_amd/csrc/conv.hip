@@ -311,11 +311,9 @@ template <int BM, int BN, int WM, int WN, int BK, int MODE, bool FG>
 int launch_igemm_fg(const ConvP& p, hipStream_t s) {
   constexpr int LDK = MODE == 0 ? BK + 4 : (MODE == 5 ? 20 : 52);
   const size_t lds = (size_t)(MODE == 4 ? 1 : 2) * (BM + BN) * LDK * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce once;
+  if (first_use_on_device(once))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
@@ -353,7 +351,7 @@ int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int K
 // Number of per-sample partial records the convolution itself can emit for a following GroupNorm with G groups
 // (0: it cannot -- split-K, direct kernels, a tile straddling two samples; use mf_gn_stats_partial_f32 then).
 int mf_conv2d_gn_parts(const MfConvDesc* d, int G) {
-  if (d && d->precision == MF_CONV_FP32_F16X2) return mf::f16x2_gn_parts(d, G);
+  if (d && (d->precision == MF_CONV_FP32_F16X2 || d->precision == MF_CONV_F16)) return mf::f16x2_gn_parts(d, G);
   Plan pl;
   if (make_plan(d, &pl) != MF_OK || !pl.igemm || G <= 0 || d->Cout % G) return 0;
   const int cpg = d->Cout / G, HW = pl.Hout * pl.Wout;
@@ -400,7 +398,7 @@ int mf_conv2d_subpixel_ok(const MfConvDesc* d) {
 }
 
 size_t mf_conv2d_workspace_bytes(const MfConvDesc* d) {
-  if (d && d->precision == MF_CONV_FP32_F16X2) return mf::f16x2_workspace_bytes(d);
+  if (d && (d->precision == MF_CONV_FP32_F16X2 || d->precision == MF_CONV_F16)) return mf::f16x2_workspace_bytes(d);
   Plan pl;
   if (make_plan(d, &pl) != MF_OK) return 0;
   if (!pl.igemm || pl.splitk <= 1) return 0;
@@ -426,7 +424,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
                        const GnOut& gn, const MfConvDesc* d, void* stream) {
   double* gn_partial = gn.partial;
   const int G = gn.G;
-  MF_REQUIRE(d && d->precision != MF_CONV_FP32_F16X2, MF_EINVAL, "conv: MF_CONV_FP32_F16X2 takes fp16-pair operands: call mf_conv2d_f16x2");
+  MF_REQUIRE(d && d->precision != MF_CONV_FP32_F16X2 && d->precision != MF_CONV_F16, MF_EINVAL,
+             "conv: MF_CONV_FP32_F16X2 / MF_CONV_F16 take fp16-pair operands: call mf_conv2d_f16x2");
   Plan pl;
   int rc = make_plan(d, &pl);
   if (rc) return rc;
@@ -463,11 +462,9 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     const int groups = cdiv(pl.M, kSmallPix);
     const int cotiles = cdiv(d->Cout, kSmallCo);
     const size_t lds = ((size_t)pl.K * kSmallCo + (size_t)kSmallPG * kSmallPix * pl.K) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;
+    if (first_use_on_device(once))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr = true;
-    }
     int gx = cdiv(groups, kSmallPG);
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);

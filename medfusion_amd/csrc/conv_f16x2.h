@@ -94,8 +94,13 @@ __device__ __forceinline__ float hz_mul(float a, float b) { float r; asm volatil
 #define MFC2_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <int BM, int BN, int WM, int WN, int NST>
+// TERMS = 3: the fp32-class arithmetic above.  TERMS = 1 (MF_CONV_F16, opt-in REDUCED precision): only main += wh * xh -- the operands
+// rounded to fp16 (11 significant bits), one matrix instruction per product, fp32 accumulate; same operand images, same DMA, the lo'
+// pieces are simply never read from LDS.
+template <int BM, int BN, int WM, int WN, int NST, int TERMS = 3>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP2 p) {
+  static_assert(TERMS == 3 || TERMS == 1, "three product terms (fp16 pairs) or one (fp16)");
+  constexpr int PC = TERMS == 3 ? 2 : 1;                    // pieces of a fragment that are read: hi and lo', or hi only
   constexpr int NW = WM * WN;   // waves per workgroup: 8 (one workgroup per CU) or 4 (two per CU: independent barrier cadences)
   static_assert(NW == 8 || NW == 4, "4 or 8 waves");
   constexpr int FM = BM / WM, FN = BN / WN, TM = FM / 32, TN = FN / 32;
@@ -103,11 +108,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   constexpr int GP = BM / (8 * NW), GQ = BN / (8 * NW), NL = GP + GQ;   // DMA instructions per wave and chunk (8 rows x 128 B each)
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile");
   constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
-  constexpr int NM = 3 * TM * TN;                           // MFMAs per 16-deep step
-  constexpr int NR = 2 * (TM + TN);                         // fragment reads per step
+  constexpr int NM = TERMS * TM * TN;                       // MFMAs per 16-deep step
+  constexpr int NR = PC * (TM + TN);                        // fragment reads per step
   constexpr int NF = (2 * NM + 2) / 3;                      // the reads of a step are issued behind its first NF MFMAs (the rest cover their latency)
   static_assert(NST >= 2 && NST <= 6 && NST * STAGE <= 160 * 1024 && (NST - 1) * NL <= 63, "LDS stages");
-  static_assert((NR + NF - 1) / NF <= 2, "at most two reads per slot");
+  static_assert((NR + NF - 1) / NF <= 3, "at most three reads per slot");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -274,11 +279,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 #define MFC2_READ_UNIT(S, SB, U)                                                                                        \
   {                                                                                                                     \
     constexpr int u_ = (U);                                                                                             \
-    if constexpr (u_ < 2 * TM) {                                                                                        \
-      fx[S][u_ / 2][u_ % 2] = *reinterpret_cast<const f16x8*>(smem + (SB) + xrow0 + (u_ / 2) * 32 * ROWB + foff[S][u_ % 2]); \
+    if constexpr (u_ < PC * TM) {                                                                                       \
+      fx[S][u_ / PC][u_ % PC] = *reinterpret_cast<const f16x8*>(smem + (SB) + xrow0 + (u_ / PC) * 32 * ROWB + foff[S][u_ % PC]); \
     } else {                                                                                                            \
-      constexpr int v_ = u_ - 2 * TM;                                                                                   \
-      fw[S][v_ / 2][v_ % 2] = *reinterpret_cast<const f16x8*>(smem + (SB) + wrow0 + (v_ / 2) * 32 * ROWB + foff[S][v_ % 2]); \
+      constexpr int v_ = u_ - PC * TM;                                                                                  \
+      fw[S][v_ / PC][v_ % PC] = *reinterpret_cast<const f16x8*>(smem + (SB) + wrow0 + (v_ / PC) * 32 * ROWB + foff[S][v_ % PC]); \
     }                                                                                                                   \
   }
 // MFMA n (0 .. NM-1) of step S: term t outer so that consecutive instructions hit different accumulators
@@ -287,8 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     constexpr int n_ = (N_);                                                                                            \
     constexpr int j_ = n_ % TN, i_ = (n_ / TN) % TM, t_ = n_ / (TN * TM);                                               \
     if constexpr (t_ == 0) accm[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][0], fx[S][i_][0], accm[i_][j_], 0, 0, 0); \
-    if constexpr (t_ == 1) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][0], fx[S][i_][1], accx[i_][j_], 0, 0, 0); \
-    if constexpr (t_ == 2) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][1], fx[S][i_][0], accx[i_][j_], 0, 0, 0); \
+    if constexpr (t_ == 1) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][0], fx[S][i_][PC - 1], accx[i_][j_], 0, 0, 0); \
+    if constexpr (t_ == 2) accx[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S][j_][PC - 1], fx[S][i_][0], accx[i_][j_], 0, 0, 0); \
   }
 
   if (nit > 0) {
@@ -305,7 +310,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
       else if (g == 3) { MFC2_WAIT_VM(3 * NL); } else if (g == 2) { MFC2_WAIT_VM(2 * NL); } else if (g == 1) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
     }
     __builtin_amdgcn_s_barrier();
-    MFC2_READ_UNIT(0, 0, 0) MFC2_READ_UNIT(0, 0, 1) MFC2_READ_UNIT(0, 0, 2) MFC2_READ_UNIT(0, 0, 3)
+    MFC2_READ_UNIT(0, 0, 0) MFC2_READ_UNIT(0, 0, 1)
+    if constexpr (NR > 2) MFC2_READ_UNIT(0, 0, NR > 2 ? 2 : 0)
+    if constexpr (NR > 3) MFC2_READ_UNIT(0, 0, NR > 3 ? 3 : 0)
     if constexpr (NR > 4) { MFC2_READ_UNIT(0, 0, NR > 4 ? 4 : 0) MFC2_READ_UNIT(0, 0, NR > 4 ? 5 : 0) }
     if constexpr (NR > 6) { MFC2_READ_UNIT(0, 0, NR > 6 ? 6 : 0) MFC2_READ_UNIT(0, 0, NR > 6 ? 7 : 0) }
   }
@@ -319,6 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(1, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(1, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
+    if constexpr (lo_ + 2 < hi_ && lo_ + 2 < NR) MFC2_READ_UNIT(1, SB, lo_ + 2 < NR ? lo_ + 2 : 0)                      \
     if constexpr ((N_) == NM - 1) MFC2_LOAD_PREP()   /* (addresses of the DMA the second half issues) */                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   }
@@ -329,16 +337,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     constexpr int lo_ = (N_) < NF ? ((N_) * NR + NF - 1) / NF : NR, hi_ = (N_) < NF ? (((N_) + 1) * NR + NF - 1) / NF : NR; \
     if constexpr (lo_ < hi_ && lo_ < NR) MFC2_READ_UNIT(0, SB, lo_ < NR ? lo_ : 0)                                      \
     if constexpr (lo_ + 1 < hi_ && lo_ + 1 < NR) MFC2_READ_UNIT(0, SB, lo_ + 1 < NR ? lo_ + 1 : 0)                      \
+    if constexpr (lo_ + 2 < hi_ && lo_ + 2 < NR) MFC2_READ_UNIT(0, SB, lo_ + 2 < NR ? lo_ + 2 : 0)                      \
     constexpr int ll_ = ((N_) * NL + NM - 1) / NM, lh_ = (((N_) + 1) * NL + NM - 1) / NM;                               \
     if (DO_LOAD) {                                                                                                      \
       if constexpr (ll_ < lh_ && ll_ < NL) MFC2_LOAD_UNIT(ll_ < NL ? ll_ : 0)                                           \
       if constexpr (ll_ + 1 < lh_ && ll_ + 1 < NL) MFC2_LOAD_UNIT(ll_ + 1 < NL ? ll_ + 1 : 0)                           \
+      if constexpr (ll_ + 2 < lh_ && ll_ + 2 < NL) MFC2_LOAD_UNIT(ll_ + 2 < NL ? ll_ + 2 : 0)                           \
+      if constexpr (ll_ + 3 < lh_ && ll_ + 3 < NL) MFC2_LOAD_UNIT(ll_ + 3 < NL ? ll_ + 3 : 0)                           \
+      if constexpr (ll_ + 4 < lh_ && ll_ + 4 < NL) MFC2_LOAD_UNIT(ll_ + 4 < NL ? ll_ + 4 : 0)                           \
+      if constexpr (ll_ + 5 < lh_ && ll_ + 5 < NL) MFC2_LOAD_UNIT(ll_ + 5 < NL ? ll_ + 5 : 0)                           \
+      if constexpr (ll_ + 6 < lh_ && ll_ + 6 < NL) MFC2_LOAD_UNIT(ll_ + 6 < NL ? ll_ + 6 : 0)                           \
+      if constexpr (ll_ + 7 < lh_ && ll_ + 7 < NL) MFC2_LOAD_UNIT(ll_ + 7 < NL ? ll_ + 7 : 0)                           \
     }                                                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
   }
 #define MFC2_REP12(M_, ...)                                                                                             \
-  M_(0, __VA_ARGS__) M_(1, __VA_ARGS__) M_(2, __VA_ARGS__)                                                              \
-  if constexpr (NM > 3) { M_(NM > 3 ? 3 : 0, __VA_ARGS__) M_(NM > 3 ? 4 : 0, __VA_ARGS__) M_(NM > 3 ? 5 : 0, __VA_ARGS__) } \
+  M_(0, __VA_ARGS__)                                                                                                    \
+  if constexpr (NM > 1) { M_(NM > 1 ? 1 : 0, __VA_ARGS__) }                                                             \
+  if constexpr (NM > 2) { M_(NM > 2 ? 2 : 0, __VA_ARGS__) }                                                             \
+  if constexpr (NM > 3 && NM <= 4) { M_(NM > 3 ? 3 : 0, __VA_ARGS__) }                                                  \
+  if constexpr (NM > 4) { M_(NM > 3 ? 3 : 0, __VA_ARGS__) M_(NM > 3 ? 4 : 0, __VA_ARGS__) M_(NM > 3 ? 5 : 0, __VA_ARGS__) } \
   if constexpr (NM > 6) { M_(NM > 6 ? 6 : 0, __VA_ARGS__) M_(NM > 6 ? 7 : 0, __VA_ARGS__) M_(NM > 6 ? 8 : 0, __VA_ARGS__)   \
                           M_(NM > 6 ? 9 : 0, __VA_ARGS__) M_(NM > 6 ? 10 : 0, __VA_ARGS__) M_(NM > 6 ? 11 : 0, __VA_ARGS__) }
 

@@ -117,19 +117,21 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   return MF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
-int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s) {
+inline bool pair_precision(int prec) { return prec == MF_CONV_FP32_F16X2 || prec == MF_CONV_F16; }   // both run on the fp16-pair operands
+
+template <int BM, int BN, int WM, int WN, int NST, int TERMS>
+int launch_f16x2_t(const mfc2::ConvP2& p, hipStream_t s) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * 128u;
-  static bool attr_set[64] = {};   // per device: the attribute belongs to the (function, device) pair
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
+  static DeviceOnce once;   // per device: the attribute belongs to the (function, device) pair
+  if (first_use_on_device(once))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_f16x2");
+}
+template <int BM, int BN, int WM, int WN, int NST>
+int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s, int terms) {
+  return terms == 1 ? launch_f16x2_t<BM, BN, WM, WN, NST, 1>(p, s) : launch_f16x2_t<BM, BN, WM, WN, NST, 3>(p, s);
 }
 
 // split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
@@ -195,7 +197,7 @@ extern "C" {
 /* ------------------------------------------------------------------ MF_CONV_FP32_F16X2 */
 int mf_conv2d_f16x2_ok(const MfConvDesc* d) {
   Plan2 pl;
-  return d && d->precision == MF_CONV_FP32_F16X2 && make_plan2(d, &pl) == MF_OK && pl.ok ? 1 : 0;
+  return d && pair_precision(d->precision) && make_plan2(d, &pl) == MF_OK && pl.ok ? 1 : 0;
 }
 
 // slots of the measured-bound array a conv writes per sample (0: it cannot measure -- a tile straddles two samples)
@@ -216,13 +218,13 @@ static int bound_slots2(const MfConvDesc* d, const Plan2& pl, bool with_stats) {
 
 int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d) {
   Plan2 pl;
-  if (!d || d->precision != MF_CONV_FP32_F16X2 || make_plan2(d, &pl) != MF_OK || !pl.ok) return 0;
+  if (!d || !pair_precision(d->precision) || make_plan2(d, &pl) != MF_OK || !pl.ok) return 0;
   return bound_slots2(d, pl, false);
 }
 
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk) {
   MF_REQUIRE(d, MF_EINVAL, "plan_query: null desc");
-  if (d->precision == MF_CONV_FP32_F16X2) {
+  if (pair_precision(d->precision)) {
     Plan2 pl;
     int rc = make_plan2(d, &pl);
     if (rc) return rc;
@@ -253,14 +255,14 @@ static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of 
 
 int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {
   Plan2 pl;
-  if (!d || d->precision != MF_CONV_FP32_F16X2 || make_plan2(d, &pl) != MF_OK || !pl.ok || !tree_possible(d, pl)) return 0;
+  if (!d || !pair_precision(d->precision) || make_plan2(d, &pl) != MF_OK || !pl.ok || !tree_possible(d, pl)) return 0;
   return cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * (pl.splitk - 1);
 }
 
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                     float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
                     const MfConvDesc* d, void* stream) {
-  MF_REQUIRE(d && d->precision == MF_CONV_FP32_F16X2, MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2");
+  MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2 (or the opt-in MF_CONV_F16)");
   Plan2 pl;
   int rc = make_plan2(d, &pl);
   if (rc) return rc;
@@ -309,19 +311,20 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
   {
-    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * 3.0);
+    const int terms = d->precision == MF_CONV_F16 ? 1 : 3;
+    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
     switch (pl.t.id) {
-      case 31: rc = launch_f16x2<128, 256, 2, 4, 3>(p, s); break;
-      case 32: rc = launch_f16x2<256, 128, 4, 2, 3>(p, s); break;
-      case 33: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s); break;
-      case 34: rc = launch_f16x2<128, 128, 4, 2, 3>(p, s); break;
-      case 35: rc = launch_f16x2<256, 64, 4, 2, 3>(p, s); break;
-      case 36: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s); break;
-      case 37: rc = launch_f16x2<64, 256, 1, 8, 3>(p, s); break;
-      case 51: rc = launch_f16x2<128, 128, 2, 2, 2>(p, s); break;
-      case 52: rc = launch_f16x2<128, 128, 2, 2, 3>(p, s); break;
-      case 53: rc = launch_f16x2<64, 128, 2, 2, 3>(p, s); break;
-      case 54: rc = launch_f16x2<128, 64, 2, 2, 3>(p, s); break;
+      case 31: rc = launch_f16x2<128, 256, 2, 4, 3>(p, s, terms); break;
+      case 32: rc = launch_f16x2<256, 128, 4, 2, 3>(p, s, terms); break;
+      case 33: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s, terms); break;
+      case 34: rc = launch_f16x2<128, 128, 4, 2, 3>(p, s, terms); break;
+      case 35: rc = launch_f16x2<256, 64, 4, 2, 3>(p, s, terms); break;
+      case 36: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s, terms); break;
+      case 37: rc = launch_f16x2<64, 256, 1, 8, 3>(p, s, terms); break;
+      case 51: rc = launch_f16x2<128, 128, 2, 2, 2>(p, s, terms); break;
+      case 52: rc = launch_f16x2<128, 128, 2, 2, 3>(p, s, terms); break;
+      case 53: rc = launch_f16x2<64, 128, 2, 2, 3>(p, s, terms); break;
+      case 54: rc = launch_f16x2<128, 64, 2, 2, 3>(p, s, terms); break;
       default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
     }
   }

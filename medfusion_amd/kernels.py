@@ -214,17 +214,18 @@ def pin_conv_plan(d: L.MfConvDesc):
     """Fix the planner's choice for `d` in its hint fields (later calls with this descriptor skip the table lookup and the cost model) and
     return what a caller needs per launch: (workspace bytes, slots of the measured-bound array, sync words of an in-launch split-K)."""
     lib = L.load()
-    if d.precision == 5 and not (d.tile_hint and d.splitk_hint):
+    if d.precision in (5, 6) and not (d.tile_hint and d.splitk_hint):
         t, k = conv_plan(d)
         if t > 0 and k > 0:
             d.tile_hint, d.splitk_hint = t, k
-    return (lib.mf_conv2d_workspace_bytes(C.byref(d)), (lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if d.precision == 5 else 0),
-            (lib.mf_conv2d_f16x2_sync_words(C.byref(d)) if d.precision == 5 else 0))
+    return (lib.mf_conv2d_workspace_bytes(C.byref(d)), (lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) if d.precision in (5, 6) else 0),
+            (lib.mf_conv2d_f16x2_sync_words(C.byref(d)) if d.precision in (5, 6) else 0))
 
 
 def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, measure_out: bool = False, gn_groups: int = 0, gn_parts: int = 0, pinned=None):
-    """MF_CONV_FP32_F16X2 convolution of fp32 NHWC tensors whose fp16-pair mirrors are made on demand.  w_split = split_weight_f16x2(...).
+    """MF_CONV_FP32_F16X2 (d.precision = 5; or the opt-in single-term MF_CONV_F16 = 6) convolution of fp32 NHWC tensors whose fp16-pair
+    mirrors are made on demand.  w_split = split_weight_f16x2(...).
     measure_out: also measure the per-sample max |y| (-> y._mf_bound: the output feeds a convolution or a residual add un-normalised).
     pinned: pin_conv_plan(d), computed once by callers that launch the same descriptor every iteration.
     Returns y, or (y, partial [N, parts, G, 2]) when gn_groups > 0 (statistics of the GroupNorm that follows)."""

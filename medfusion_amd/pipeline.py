@@ -333,6 +333,11 @@ class DiffusionPipeline(nn.Module):
                 kwargs["un_cond"] = kwargs["un_cond"][lo:hi]
         if noise is None:
             noise = default_noise()
+        if hi == lo:   # more ranks than samples: this rank's shard is empty -- no launch, the gather pads it (dist.gather_images)
+            empty = torch.empty((0, *img_size), dtype=torch.float32, device=dev)
+            if kwargs.get("decode", True) and self.latent_embedder is not None:
+                return self.latent_embedder.decode(empty)
+            return empty
         with torch.cuda.device(dev):   # launches go to the CURRENT device's stream: make the pipeline's device current for the call
             noise.begin(hi - lo, dev, sample_offset=lo, global_batch=num_samples)
             x_T = noise.draw((hi - lo, *img_size))  # noise_scheduler.x_final(template): draw #0 (Q3)

@@ -32,6 +32,10 @@ class VAE(nn.Module):
         use_attention = use_attention if isinstance(use_attention, list) else [use_attention] * len(strides)
         self.depth = len(strides)
         self.emb_channels = emb_channels
+        self.out_channels = out_channels
+        self.scale = 1                       # spatial factor between the latent and the image
+        for st in strides:
+            self.scale *= int(st)
         ConvBlock = UnetResBlock if use_res_block else UnetBasicBlock
         self.inc = ConvBlock(spatial_dims, in_channels, hid_chs[0], kernel_size=kernel_sizes[0], stride=strides[0], act_name=act_name,
                              norm_name=norm_name, emb_channels=None)
@@ -74,6 +78,8 @@ class VAE(nn.Module):
         """z [B,emb,h,w] NCHW -> x [B,3,8h,8w] NCHW."""
         if not z.is_cuda:
             raise RuntimeError("medfusion_amd.VAE runs on a ROCm device only (no CPU fallback)")
+        if z.shape[0] == 0:   # an empty shard of a multi-GPU batch (more ranks than samples): nothing to launch
+            return z.new_empty((0, self.out_channels, z.shape[2] * self.scale, z.shape[3] * self.scale))
         K.SyncWords.reset(z.device)
         h = self.inc_dec(z.contiguous(), None, in_layout=L.LAYOUT_NCHW)
         for i in range(len(self.decoders), 0, -1):

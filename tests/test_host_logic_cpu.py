@@ -122,12 +122,16 @@ def _worker(rank, world, port, n, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [6, 5])
-def test_two_process_gloo_shard_and_gather(tmp_path, n):
-    port = 29600 + os.getpid() % 300 + n
-    mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
-    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
-    assert torch.equal(a, b) and a.shape == (n, 2, 4, 4)
+@pytest.mark.parametrize("world,n", [(2, 6), (2, 5), (8, 5), (8, 16)])
+def test_multi_process_gloo_shard_and_gather(tmp_path, world, n):
+    """world 2 (even / uneven shards) and world 8 -- the node size of the metric -- incl. n = 5 over 8 ranks: three ranks own NO row, their
+    empty shard is padded for the collective and trimmed after it (dist.gather_images)"""
+    port = 29600 + os.getpid() % 300 + n + 16 * world
+    mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    a, b = outs[0], outs[-1]
+    assert all(torch.equal(a, o) for o in outs) and a.shape == (n, 2, 4, 4)
+    assert [D.shard_rows(5, r, 8) for r in range(8)] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]
     # equals the single-process run of the global batch (shard invariance)
     noise = M.HostNoise(lambda shape: S.PhiloxNoise(11)(torch.empty(tuple(shape))))
     want = _FakePipe().sample(n, (2, 4, 4), condition=torch.arange(n) % 3, noise=noise, shard=(0, 1))

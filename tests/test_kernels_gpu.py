@@ -630,6 +630,41 @@ def test_conv_f16x2(dev, case, tile):
         assert relerr(yb, wantb) < 1e-5, (case, tile)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 32, 64, 3, 1, 0), (1, 16, 16, 256, 0, 256, 3, 1, 0), (2, 8, 8, 512, 512, 512, 3, 1, 0), (2, 8, 8, 64, 0, 128, 1, 1, 0),
+                                  (2, 5, 6, 32, 0, 64, 3, 1, 2), (3, 10, 12, 32, 0, 64, 3, 2, 0)])
+def test_conv_f16_single_term(dev, case):
+    """MF_CONV_F16 (opt-in REDUCED precision): the fp16-pair operands and the LDS-DMA kernel with ONE product term, i.e. the
+    operands rounded to fp16 -- on every tile and split-K the fp16-pair mode takes: error vs fp64 within the mode's own tolerance (2^-11 per
+    operand), bit-reproducible, statistics / bounds like the fp32-class mode, and exactly the convolution of the fp16-rounded operands."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups = case
+    x = _rand(f"hx{case}", (n, c1, h, w))
+    x2 = _rand(f"hy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"hw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k))
+    b = _rand(f"hb{case}", (co,), 0.1)
+    pad = R.monai_padding(k, stride)
+    want = _conv_ref(x, x2, wt, b, stride, pad, 1 if ups else 0)
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    wp = K.pack_upconv_weight(wt.to(dev)) if ups == 2 else K.pack_conv_weight(wt.to(dev))
+    wh = K.split_weight_f16x2(wp)
+    first = None
+    for tile in _f16x2_tiles(case):
+        for sk in ([0] if tile == 0 else [1, 2, 4]):
+            if sk > (c1 + c2) // 32:
+                continue
+            d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=6)
+            assert K.conv_f16x2_ok(d), (case, tile, sk)
+            y = K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d, measure_out=True)
+            e = relerr(K.nhwc_to_nchw(y), want)
+            assert 1e-6 < e < 2e-3, (case, tile, sk, e)      # reduced precision: clearly not the fp32 class, clearly inside its own
+            assert torch.equal(y, K.conv2d_f16x2(xd, wh, b.to(dev), d, x2=x2d)), (case, tile, sk)
+            assert torch.equal(K.bound_of(y), y.abs().amax(dim=(1, 2, 3))), (case, tile, sk)
+            if sk <= 1:   # one accumulation chain per element: the same bits on every tile
+                first = y if first is None else first
+                assert torch.equal(y, first), (case, tile)
+
+
 def test_gn_apply_split_mirror(dev):
     """gn_apply(split=True) writes the fp16-pair mirror of exactly what it writes in fp32, scaled by the bound it derives and
     publishes: bconst + bound(residual) + bound(embedding row) >= max |out|"""

@@ -41,7 +41,7 @@ pipe.latent_embedder = VAE(in_channels=3, out_channels=3, emb_channels=8, spatia
 P.seeded_fill(pipe.noise_estimator, "mp.unet.")
 P.seeded_fill(pipe.latent_embedder, "mp.vae.")
 pipe.to(dev).eval()
-n = 5                                            # odd: the shards differ by one row
+n = 5                                            # odd: the shards differ by one row; with 8 ranks three shards are EMPTY
 cond = (torch.arange(n, device=dev) % 3)
 full = D.sample_sharded(pipe, n, (8, 8, 8), condition=cond, noise=M.PhiloxDeviceNoise(31), guidance_scale=4.0, un_cond=None, steps=3, use_ddim=True)
 assert full.shape == (n, 3, 64, 64) and full.device == dev
@@ -76,6 +76,14 @@ def _launch(backend, world, ngpu, tmp_path):
 def test_two_ranks_sharing_one_gpu_gather_over_gloo(tmp_path):
     assert torch.cuda.is_available()
     _launch("gloo", 2, 1, tmp_path)
+
+
+def test_eight_ranks_sharing_one_gpu_with_empty_shards(tmp_path):
+    """the world size of the metric's node: 5 samples over 8 ranks -- ranks 5..7 own no row, launch nothing, and still take part in the
+    gather (pad / trim of dist.gather_images); every rank ends with the 5 images of the single-process run"""
+    assert torch.cuda.is_available()
+    out = _launch("gloo", 8, 1, tmp_path)
+    assert "MULTIPROC_OK 8 gloo" in out
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs for the RCCL transport")

@@ -444,6 +444,35 @@ def test_bf16_opt_in_mode_has_its_own_tolerance(dev, published, conv_precision):
         BLK.CONV_PRECISION = conv_precision
 
 
+F16_TOL = 1e-2
+
+
+@torch.no_grad()
+def test_f16_single_term_opt_in_mode_has_its_own_tolerance(dev, published, conv_precision):
+    """MF_CONV_F16 (opt-in, on the LDS-DMA kernel of the default arithmetic): one UNet evaluation and a 20-iteration
+    trajectory at the published size against the fp32 oracle, with the mode's own tolerance (operands carry 11 significant bits)."""
+    if conv_precision != 1:
+        pytest.skip("runs once")
+    from medfusion_amd import blocks as BLK
+    ora, pipe = published
+    BLK.CONV_PRECISION = 6
+    try:
+        x = S.synth_input("pub256_x", (2, 8, 32, 32))
+        t = torch.tensor([731, 731])
+        want, _ = ora.noise_estimator(x, t, None)
+        got, _ = pipe.noise_estimator(x.to(dev), t.to(dev), None)
+        e_unet = relerr(got, want)
+        ora.set_noise_fn(S.PhiloxNoise(77))
+        tr_o, tr_p = [], []
+        want_img = ora.sample(1, (8, 32, 32), steps=20, use_ddim=True, trace=tr_o)
+        got_img = pipe.sample(1, (8, 32, 32), steps=20, use_ddim=True, noise=oracle_noise(77), trace=tr_p)
+        errs = [relerr(a[0], b[0]) for a, b in zip(tr_p, tr_o)]
+        print(f"fp16 single-term mode: UNet {e_unet:.1e} | x0 along 20 iterations: " + " ".join(f"{e:.1e}" for e in errs[::3]) + f" | image {relerr(got_img, want_img):.1e}")
+        assert 1e-5 < e_unet < F16_TOL and max(errs) < F16_TOL and relerr(got_img, want_img) < F16_TOL
+    finally:
+        BLK.CONV_PRECISION = conv_precision
+
+
 @torch.no_grad()
 def test_cold_diffusion_through_the_loop(dev):
     """`denoise(..., cold_diffusion=True)` (the reference forwards the flag to forward() on every iteration, diffusion_pipeline.py:294):

@@ -70,10 +70,19 @@ def test_precision_enum_matches_header():
     import re
     from pathlib import Path
     txt = (Path(__file__).resolve().parents[1] / "include" / "medfusion_hip.h").read_text()
-    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d), MF_CONV_FP32_F16X2 = (\d) \}", txt)
-    assert m and [int(v) for v in m.groups()] == [0, 3, 4, 5]
+    m = re.search(r"enum \{ MF_CONV_FP32 = (\d), MF_CONV_FP32_SPLIT3_W3 = (\d), MF_CONV_BF16 = (\d), MF_CONV_FP32_F16X2 = (\d), MF_CONV_F16 = (\d) \}", txt)
+    assert m and [int(v) for v in m.groups()] == [0, 3, 4, 5, 6]
     from medfusion_amd import blocks as BLK
-    assert BLK.CONV_PRECISION in (0, 1, 5)  # the reduced-precision mode (4) is never a default
+    assert BLK.CONV_PRECISION in (0, 1, 5)  # the reduced-precision modes (4, 6) are never a default
+    # the single-term fp16 mode plans like the fp16-pair mode it shares its kernel and operands with
+    lib = L.load()
+    for prec in (5, 6):
+        d = _d(16, 32, 32, 256, 0, 256, prec=prec)
+        assert lib.mf_conv2d_f16x2_ok(C.byref(d)) == 1
+    t5, k5, t6, k6 = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    lib.mf_conv2d_plan_query(C.byref(_d(16, 16, 16, 512, 0, 512, prec=5)), C.byref(t5), C.byref(k5))
+    lib.mf_conv2d_plan_query(C.byref(_d(16, 16, 16, 512, 0, 512, prec=6)), C.byref(t6), C.byref(k6))
+    assert (t5.value, k5.value) == (t6.value, k6.value) and t5.value > 0
 
 
 def test_planner_properties_over_many_descriptors():
