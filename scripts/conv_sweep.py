@@ -64,7 +64,7 @@ _WH = {}
 
 
 def time_conv(x1, x2, w, b, d, reps):
-    if d.precision == 5:
+    if d.precision in (5, 6):
         k = w.data_ptr()
         if k not in _WH:
             _WH.clear()
@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--quick", action="store_true", help="auto config only")
     ap.add_argument("--only", default="", help="substring filter on the shape name")
-    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 3: fp32 split exactly into 3 bf16 terms (weights split at load), 4: bf16 (opt-in), 5: fp16 pairs (LDS-DMA kernel)")
+    ap.add_argument("--precision", type=int, default=0, help="0: fp32 MFMA, 3: fp32 split exactly into 3 bf16 terms (weights split at load), 4: bf16 (opt-in), 5: fp16 pairs (LDS-DMA kernel), 6: single-term fp16 on the same kernel (opt-in)")
     ap.add_argument("--tiles", default="", help="comma list of tile ids to sweep (default: all built for the precision)")
     ap.add_argument("--latent", type=int, default=32, help="UNet input size (32: 256-px models, 64: 512-px)")
     ap.add_argument("--emit-table", default="", help="append the best (tile, split-K) of every shape to this file as planner table entries (precision 5)")
@@ -117,7 +117,7 @@ def main():
         if args.only and args.only not in name:
             continue
         pad = 1 if k == 3 else 0
-        if args.precision == 5 and ups:
+        if args.precision in (5, 6) and ups:
             ups = 2
         x1 = torch.randn((n, h, w_, c1), generator=g).to(dev)
         x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
@@ -127,14 +127,14 @@ def main():
         ho, wo = K.conv_out_hw(d0)
         M, Kk = n * ho * wo, k * k * (c1 + c2)
         gf = 2.0 * M * co * Kk / 1e9
-        if args.precision == 5 and not K.conv_f16x2_ok(d0):
+        if args.precision in (5, 6) and not K.conv_f16x2_ok(d0):
             print(f"{name:24s} not on the fp16-pair kernel")
             continue
         time_conv(x1, x2, wt, b, d0, args.reps)  # clock/cache warm-up
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54) if args.precision == 5 else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
+            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54) if args.precision in (5, 6) else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
                 bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 51: 128, 52: 128, 53: 128, 54: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
                 bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 51: 128, 52: 128, 53: 64, 54: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
@@ -147,9 +147,9 @@ def main():
                 for sk in (1, 2, 4, 8, 16):
                     if sk > 1 and Kk // 32 // sk < 8:
                         continue
-                    if args.precision == 5 and sk > (c1 + c2) // 32:
+                    if args.precision in (5, 6) and sk > (c1 + c2) // 32:
                         continue
-                    if args.precision == 5 and -(-((c1 + c2) // 32) // sk) * (4 if ups == 2 else k * k) > 96:
+                    if args.precision in (5, 6) and -(-((c1 + c2) // 32) // sk) * (4 if ups == 2 else k * k) > 96:
                         continue   # one accumulation chain <= 96 chunks (profiles/r02_split_accuracy.txt)
                     d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))

@@ -28,6 +28,7 @@ from tests.util import T, gold, oracle_noise, relerr
 ROOT = Path(__file__).resolve().parents[1]
 CKPT = ROOT / "tests" / "golden" / "ckpt" / "runs"
 TOL = 1e-4
+GUIDED_HARNESS_TOL = 1e-3   # guidance 8 on the published widths; tightened from the values measured on MI355X (see the prints)
 
 
 @pytest.fixture(scope="module")
@@ -102,7 +103,9 @@ def test_sample_script_is_pinned_against_the_oracle(dev, tmp_path, conv_precisio
         want = ora.sample(4, (8, 32, 32), guidance_scale=8, condition=c, un_cond=None, steps=3, use_ddim=True)
         got = raw[str(cond)]
         assert got.shape == (4, 3, 256, 256)
-        assert relerr(got, want) < (1e-3 if cond is not None else TOL), cond   # guidance 8 amplifies perturbations (tests/test_parity_gpu.py)
+        e = relerr(got, want)
+        print(f"[measured] sample.py harness, condition {cond}: {e:.1e}")
+        assert e < (GUIDED_HARNESS_TOL if cond is not None else TOL), cond   # guidance 8 (tests/test_parity_gpu.py has the measured values)
     stats = {k: (float(v.min()), float(v.max()), float(v.mean())) for k, v in raw.items()}
     out2 = tmp_path / "samples2"
     _run(["scripts/sample.py", "--synthetic", "--steps", "3", "--n", "4", "--out", str(out2)], MEDFUSION_CONV_PRECISION=conv_precision)
@@ -167,7 +170,9 @@ def test_cfg3_at_the_per_gpu_workload(dev):
         tr = []
         ora.sample(2, (8, 32, 32), condition=cond[:2].cpu(), guidance_scale=8.0, un_cond=None, steps=4, use_ddim=True, trace=tr)
         want = tr[-1][1]
-    assert relerr(full[:2], want) < 1e-3
+    e = relerr(full[:2], want)
+    print(f"[measured] cfg3 at the per-GPU workload, rows 0-1 vs oracle: {e:.1e}")
+    assert e < GUIDED_HARNESS_TOL
     g1 = pipe.sample(16, (8, 32, 32), condition=cond, noise=M.PhiloxDeviceNoise(99), steps=2, use_ddim=True, guidance_scale=1.0, un_cond=None)
     assert g1.shape == (16, 3, 256, 256) and bool(g1.isfinite().all())
 
