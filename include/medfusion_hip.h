@@ -307,6 +307,23 @@ const char* mf_prof_family_name(int family);
  * pipe is power-limited by the data it multiplies, and bench.py reports the conv kernel against both numbers. */
 int mf_mfma_rate_probe_f16(const void* operands, float* out, int workgroups, int iters, double* flops, void* stream);
 
+/* ------------------------------------------------------------------ command lists (ABI 210): the loop body of denoise() replayed from C
+ * Replaces the Python loop of diffusion_pipeline.py:290-305 for every iteration after the second: the host side of one iteration is ~160
+ * launches through this ABI (2.0 ms of Python -> ctypes work, profiles/r02_host_enqueue_time.txt), all of whose per-iteration values -- t,
+ * the scheduler record, the Philox draw indices, the rows of the hoisted embedding table -- come from a DEVICE step counter that the
+ * iteration advances itself.  mf_cmdlist_begin() makes the calling thread record every launch it issues through this library (the
+ * launches still execute): kernel, grid, block, LDS size and a copy of the kernarg bytes, in issue order.  mf_cmdlist_end() returns the
+ * list; mf_cmdlist_replay(list, times, stream) re-issues it `times` times on `stream` -- plain stream-ordered launches (no graph node
+ * latency), ~1 us of host time each.  The caller guarantees what a graph capture would: every pointer recorded stays valid and means the
+ * same buffer during the replays (pipeline.py records inside a private torch memory pool), and nothing but launches of this library makes
+ * up the iteration.  Not recorded: hipFuncSetAttribute (done by the eager warm-up iteration), launch timing (begin refuses while
+ * mf_prof_enable is on).  Lists are immutable after end(), replay is thread-safe, free() releases. */
+int mf_cmdlist_begin(void);
+int mf_cmdlist_end(void** list);
+int mf_cmdlist_count(const void* list);
+int mf_cmdlist_replay(const void* list, int times, void* stream);
+int mf_cmdlist_free(void* list);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 
 #include <mutex>
 #include <string>
+#include <string.h>
 #include <vector>
 
 namespace mf {
@@ -14,6 +15,34 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- command lists (common.h: MF_LAUNCH)
+struct CmdEntry {
+  const void* func;
+  dim3 grid, block;
+  size_t lds;
+  size_t blob_off;            // first kernarg byte of this launch inside CmdList::blob
+  int nargs;
+  size_t arg_off_first;       // index of this launch's first entry in CmdList::arg_off
+};
+struct CmdList {
+  std::vector<CmdEntry> entries;
+  std::vector<unsigned char> blob;     // kernarg copies, each at its own alignment
+  std::vector<size_t> arg_off;         // byte offset of every argument inside blob
+};
+static thread_local CmdList* g_rec = nullptr;
+CmdList* recording_list() { return g_rec; }
+
+void cmdlist_add(CmdList* cl, const void* func, dim3 grid, dim3 block, size_t lds, void* const* argv, const size_t* sizes, const size_t* aligns, int n) {
+  CmdEntry e{func, grid, block, lds, cl->blob.size(), n, cl->arg_off.size()};
+  for (int i = 0; i < n; ++i) {
+    size_t off = (cl->blob.size() + aligns[i] - 1) / aligns[i] * aligns[i];
+    cl->blob.resize(off + sizes[i]);
+    memcpy(cl->blob.data() + off, argv[i], sizes[i]);
+    cl->arg_off.push_back(off);
+  }
+  cl->entries.push_back(e);
 }
 
 struct ProfRec {
@@ -137,6 +166,51 @@ int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, dou
   return MF_OK;
 }
 
+/* ---- command lists: record the launches of one loop iteration, replay them from C (include/medfusion_hip.h) */
+int mf_cmdlist_begin(void) {
+  MF_REQUIRE(g_rec == nullptr, MF_EINVAL, "cmdlist_begin: this thread is already recording");
+  MF_REQUIRE(!g_prof, MF_EINVAL, "cmdlist_begin: launch timing (mf_prof_enable) is on -- replayed launches would not be timed");
+  g_rec = new CmdList();
+  return MF_OK;
+}
+
+int mf_cmdlist_end(void** list) {
+  MF_REQUIRE(g_rec != nullptr && list, MF_EINVAL, "cmdlist_end: not recording");
+  *list = g_rec;
+  g_rec = nullptr;
+  return MF_OK;
+}
+
+int mf_cmdlist_count(const void* list) { return list ? (int)static_cast<const CmdList*>(list)->entries.size() : 0; }
+
+int mf_cmdlist_replay(const void* list, int times, void* stream) {
+  MF_REQUIRE(list && times >= 0, MF_EINVAL, "cmdlist_replay: bad args");
+  MF_REQUIRE(g_rec == nullptr, MF_EINVAL, "cmdlist_replay: this thread is recording");
+  const CmdList* cl = static_cast<const CmdList*>(list);
+  std::vector<void*> argv;
+  // kernarg pointers point into the list's own blob (hipLaunchKernel copies the bytes at launch time)
+  unsigned char* base = const_cast<unsigned char*>(cl->blob.data());
+  size_t most = 0;
+  for (const CmdEntry& e : cl->entries) most = e.nargs > (int)most ? (size_t)e.nargs : most;
+  argv.resize(most + 1);
+  hipStream_t s = (hipStream_t)stream;
+  for (int t = 0; t < times; ++t)
+    for (const CmdEntry& e : cl->entries) {
+      for (int i = 0; i < e.nargs; ++i) argv[i] = base + cl->arg_off[e.arg_off_first + i];
+      const hipError_t err = hipLaunchKernel(e.func, e.grid, e.block, argv.data(), e.lds, s);
+      if (err != hipSuccess) {
+        set_error("cmdlist_replay: launch failed: %s", hipGetErrorString(err));
+        return MF_ELAUNCH;
+      }
+    }
+  return MF_OK;
+}
+
+int mf_cmdlist_free(void* list) {
+  delete static_cast<CmdList*>(list);
+  return MF_OK;
+}
+
 const char* mf_prof_family_name(int f) {
   static const char* names[MF_FAM_COUNT] = {"conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply",
                                             "linear", "sched", "noise", "attention", "misc"};
@@ -145,7 +219,7 @@ const char* mf_prof_family_name(int f) {
 
 int mf_mfma_rate_probe_f16(const void* operands, float* out, int workgroups, int iters, double* flops, void* stream) {
   MF_REQUIRE(operands && out && workgroups > 0 && iters > 0, MF_EINVAL, "mfma_rate_probe: bad args");
-  hipLaunchKernelGGL(mfma_rate_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<const pr_f16x8*>(operands), out, iters);
+  MF_LAUNCH(mfma_rate_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<const pr_f16x8*>(operands), out, iters);
   if (flops) *flops = (double)workgroups * 8.0 * 4.0 * (double)iters * 32768.0;
   return check_launch("mfma_rate_probe");
 }

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float* __rest
 
 template <int D>
 static int launch_attention_mfma(const float* q, const float* k, const float* v, float* out, int B, int H, int Nq, int Nk, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(attention_mfma_kernel<D>, dim3((Nq + 127) / 128, H, B), dim3(256), 0, s, q, k, v, out, H, Nq, Nk, scale);
+  MF_LAUNCH(attention_mfma_kernel<D>, dim3((Nq + 127) / 128, H, B), dim3(256), 0, s, q, k, v, out, H, Nq, Nk, scale);
   return check_launch("attention_mfma");
 }
 
@@ -247,7 +247,7 @@ int mf_attention_f32(const float* q, const float* k, const float* v, float* out,
   static DeviceOnce once;
   if (first_use_on_device(once))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(attention_kernel, dim3((Nq + kWaves * kQPerWave - 1) / (kWaves * kQPerWave), H, B), dim3(256), lds, s, q, k, v, out, H, Nq,
+  MF_LAUNCH(attention_kernel, dim3((Nq + kWaves * kQPerWave - 1) / (kWaves * kQPerWave), H, B), dim3(256), lds, s, q, k, v, out, H, Nq,
                      Nk, d, scale);
   return check_launch("attention");
 }

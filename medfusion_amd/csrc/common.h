@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/medfusion_hip.h"
 
@@ -22,6 +25,32 @@ struct ProfScope {
   hipStream_t stream;
 };
 bool prof_on();
+
+// ---- every kernel of the library is launched through MF_LAUNCH: an ordinary hipLaunchKernel -- and, while a command list records on the
+// calling thread (mf_cmdlist_begin), the same launch plus a copy of (kernel, geometry, kernarg bytes).  mf_cmdlist_replay re-issues the
+// recorded launches from C in their recorded order: the denoise loop's iteration (~160 launches, all of whose per-iteration values come
+// from a device step counter) costs ~1 us of host time per launch instead of a Python -> ctypes round trip each.
+struct CmdList;
+CmdList* recording_list();   // api.hip; null when this thread is not recording
+void cmdlist_add(CmdList* cl, const void* func, dim3 grid, dim3 block, size_t lds, void* const* argv, const size_t* sizes, const size_t* aligns, int n);
+
+template <typename... KArgs, typename... Args, size_t... I>
+inline void launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, std::index_sequence<I...>, Args&&... args) {
+  std::tuple<std::decay_t<KArgs>...> v{static_cast<std::decay_t<KArgs>>(std::forward<Args>(args))...};   // the kernel's own parameter types
+  void* argv[sizeof...(KArgs) + 1] = {static_cast<void*>(&std::get<I>(v))..., nullptr};
+  if (CmdList* cl = recording_list()) {
+    const size_t sizes[sizeof...(KArgs) + 1] = {sizeof(std::decay_t<KArgs>)..., 0};
+    const size_t aligns[sizeof...(KArgs) + 1] = {alignof(std::decay_t<KArgs>)..., 0};
+    cmdlist_add(cl, reinterpret_cast<const void*>(kernel), grid, block, lds, argv, sizes, aligns, (int)sizeof...(KArgs));
+  }
+  (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, s);
+}
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  launch_impl(kernel, grid, block, lds, s, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
+#define MF_LAUNCH(kernel, grid, block, lds, stream, ...) ::mf::launch(kernel, grid, block, lds, stream, __VA_ARGS__)
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

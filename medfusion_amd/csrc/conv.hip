@@ -315,7 +315,7 @@ int launch_igemm_fg(const ConvP& p, hipStream_t s) {
   if (first_use_on_device(once))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  MF_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, BK, MODE, FG>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_igemm");
 }
 
@@ -344,7 +344,7 @@ int mf_pack_conv_weight_f32(const float* w, float* out, int Cout, int Cin, int K
   const long total = (long)Cout * Cin * KH * KW;
   ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * total);
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, KH, KW);
+  MF_LAUNCH(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin, KH, KW);
   return check_launch("pack_conv_weight");
 }
 
@@ -364,7 +364,7 @@ int mf_pack_upconv_weight_f32(const float* w, float* out, int Cout, int Cin, voi
   MF_REQUIRE(w && out && Cout > 0 && Cin > 0, MF_EINVAL, "pack_upconv_weight: bad args");
   const long total = 16L * Cout * Cin;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_upconv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
+  MF_LAUNCH(pack_upconv_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, out, Cout, Cin);
   return check_launch("pack_upconv_weight");
 }
 
@@ -378,7 +378,7 @@ int mf_split_conv_weight_bf16x3(const float* w_packed, void* out, long rows, int
   const long octets = rows * (K / 8);
   ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 10.0 * rows * K);
   const int blocks = (int)((octets + 255) / 256 > 4096 ? 4096 : (octets + 255) / 256);
-  hipLaunchKernelGGL(split_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x4*>(out), octets);
+  MF_LAUNCH(split_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x4*>(out), octets);
   return check_launch("split_conv_weight");
 }
 
@@ -387,7 +387,7 @@ int mf_convert_conv_weight_bf16(const float* w_packed, void* out, long rows, int
   const long quads = rows * (K / 4);
   ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 6.0 * rows * K);
   const int blocks = (int)((quads + 255) / 256 > 4096 ? 4096 : (quads + 255) / 256);
-  hipLaunchKernelGGL(convert_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x2*>(out), quads);
+  MF_LAUNCH(convert_weight_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_packed, reinterpret_cast<u32x2*>(out), quads);
   return check_launch("convert_conv_weight_bf16");
 }
 
@@ -467,7 +467,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int gx = cdiv(groups, kSmallPG);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
+    MF_LAUNCH(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
     return check_launch("conv_smallcin");
   }
   if (!pl.igemm) {
@@ -475,9 +475,9 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     const long total = (long)pl.M * d->Cout;
     const int blocks = (int)((total + 255) / 256);
     if (p.out_nchw)
-      hipLaunchKernelGGL(conv_direct_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+      MF_LAUNCH(conv_direct_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
     else
-      hipLaunchKernelGGL(conv_direct_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+      MF_LAUNCH(conv_direct_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
     return check_launch("conv_direct");
   }
 
@@ -548,8 +548,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
       const int HW = pl.Hout * pl.Wout;
       ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
       const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
-      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
-                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y);
+      MF_LAUNCH(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
+                         reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, (float*)nullptr);
       return check_launch("splitk_reduce_stats");
     }
     const long p4 = (long)pl.Hout * pl.Wout * d->Cout / 4;   // float4s per sample
@@ -557,7 +557,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     int bx = (int)((p4 + 255) / 256);
     const int cap = cdiv(2048, d->N);
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
+    MF_LAUNCH(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
                        pl.splitk, p.slab, (float*)nullptr);
     return check_launch("splitk_reduce");
   }

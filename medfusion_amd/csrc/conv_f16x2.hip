@@ -126,7 +126,7 @@ int launch_f16x2_t(const mfc2::ConvP2& p, hipStream_t s) {
   if (first_use_on_device(once))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  MF_LAUNCH((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_f16x2");
 }
 template <int BM, int BN, int WM, int WN, int NST>
@@ -240,7 +240,7 @@ int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64
   const long octets = (long)rows * (per_row / 8);
   ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * rows * (double)per_row);
   const int blocks = (int)((octets + 255) / 256 > 8192 ? 8192 : (octets + 255) / 256);
-  hipLaunchKernelGGL(mfc2::split_act_f16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), octets, bound,
+  MF_LAUNCH(mfc2::split_act_f16x2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), octets, bound,
                      (long)(per_row / 8));
   return check_launch("split_f16x2");
 }
@@ -334,7 +334,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     ProfScope ps(MF_FAM_SPLITK_REDUCE, s, 0, 4.0 * pl.M * d->Cout * (pl.splitk + 1));
     if (gn_partial) {  // reduction + bias + GroupNorm partial statistics (+ measured bound) in one streaming pass
       const int slices = stats_slices(d->N, HW, d->Cout, G), chunks = stats_chunks(HW);
-      hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
+      MF_LAUNCH(gn_partial_kernel<true>, dim3(chunks, d->N, slices), dim3(kStatsThreads), stats_lds_bytes(d->Cout / slices), s,
                          reinterpret_cast<const float*>(workspace), gn_partial, HW, d->Cout, G, pl.splitk, p.slab, bias, y, (float*)nullptr);
       return check_launch("splitk_reduce_stats");
     }
@@ -342,7 +342,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
     int bx = (int)((p4 + 255) / 256);
     const int cap = cdiv(2048, d->N);
     if (bx > cap) bx = cap;
-    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
+    MF_LAUNCH(splitk_reduce_kernel<0>, dim3(bx, d->N), dim3(256), 0, s, reinterpret_cast<const float*>(workspace), bias, y, p4, d->Cout,
                        pl.splitk, p.slab, y_bound);
     return check_launch("splitk_reduce");
   }

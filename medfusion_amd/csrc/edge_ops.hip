@@ -109,7 +109,7 @@ int mf_rows_axpby_f32(const float* x, const float* y, const float* a, const floa
   ProfScope ps(MF_FAM_SCHED, s, 3.0 * total, 12.0 * total);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(rows_axpby_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, a, c, d, out, (long)per_row, total, do_clamp, lo, hi);
+  MF_LAUNCH(rows_axpby_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, a, c, d, out, (long)per_row, total, do_clamp, lo, hi);
   return check_launch("rows_axpby");
 }
 
@@ -122,13 +122,13 @@ int mf_image_egress_u8(const float* x_nchw, uint8_t* out_nhwc, float* minmax_ws,
   ProfScope ps(MF_FAM_MISC, s, 4.0 * total, 5.0 * total);
   const int blocks = (int)((total + 255) / 256);
   if (mode == 0) {
-    hipLaunchKernelGGL(image_u8_dataset_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, out_nhwc, N, C, H, W);
+    MF_LAUNCH(image_u8_dataset_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, out_nhwc, N, C, H, W);
     return check_launch("image_egress");
   }
-  hipLaunchKernelGGL(image_minmax_kernel, dim3(N), dim3(256), 0, s, x_nchw, minmax_ws, (long)C * H * W);
+  MF_LAUNCH(image_minmax_kernel, dim3(N), dim3(256), 0, s, x_nchw, minmax_ws, (long)C * H * W);
   int rc = check_launch("image_minmax");
   if (rc) return rc;
-  hipLaunchKernelGGL(image_u8_normalized_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, minmax_ws, out_nhwc, N, C, H, W);
+  MF_LAUNCH(image_u8_normalized_kernel, dim3(blocks), dim3(256), 0, s, x_nchw, minmax_ws, out_nhwc, N, C, H, W);
   return check_launch("image_egress_normalized");
 }
 

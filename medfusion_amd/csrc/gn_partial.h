@@ -59,7 +59,7 @@ __device__ __forceinline__ float4 sum_slabs(const float* __restrict__ p, long sl
 template <bool REDUCE>
 __global__ __launch_bounds__(kStatsThreads) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int HW, int C, int G,
                                                                    int nslabs, long slab, const float* __restrict__ bias, float* __restrict__ y,
-                                                                   float* __restrict__ out_bound = nullptr) {
+                                                                   float* __restrict__ out_bound) {
   extern __shared__ __attribute__((aligned(16))) float sh[];  // [rowphases][Cs][2]
   const int chunks = gridDim.x, chunk = blockIdx.x, n = blockIdx.y;
   const int Cs = C / gridDim.z, c_off = blockIdx.z * Cs;  // this workgroup's channel slice

@@ -256,12 +256,12 @@ int mf_gn_stats_f32(const float* x, float* stats, void* workspace, size_t worksp
   const size_t lds = stats_lds_bytes(C / slices);
   MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats: C=%d too wide", C);
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
-  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G, 1, 0L,
-                     (const float*)nullptr, (float*)nullptr);
+  MF_LAUNCH(gn_partial_kernel<false>, dim3(chunks, N, slices), dim3(kStatsThreads), lds, s, x, reinterpret_cast<double*>(workspace), HW, C, G, 1, 0L,
+                     (const float*)nullptr, (float*)nullptr, (float*)nullptr);
   int rc = check_launch("gn_stats_partial");
   if (rc) return rc;
   const int NG = N * G;
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double*>(workspace), stats, NG, G,
+  MF_LAUNCH(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<const double*>(workspace), stats, NG, G,
                      chunks, (double)HW * (C / G), eps);
   return check_launch("gn_stats_final");
 }
@@ -292,13 +292,13 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
     const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound, nullptr, 0};
-    hipLaunchKernelGGL(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
+    MF_LAUNCH(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
                        C, G > 0 ? G : 1, act, sp);
     return check_launch("gn_apply_split");
   }
   long blocks = (total4 + 255) / 256;
   if (blocks > 256 * 8) blocks = 256 * 8;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
+  MF_LAUNCH(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW, C,
                      G > 0 ? G : 1, act);
   return check_launch("gn_apply");
 }
@@ -325,10 +325,10 @@ int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int 
   const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots};
   const double count = (double)HW * (C / G);
   if (out_split)
-    hipLaunchKernelGGL(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
+    MF_LAUNCH(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
                        (long)emb_stride, out, HW, C, G, act, sp);
   else
-    hipLaunchKernelGGL(gn_apply_part_kernel<false>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
+    MF_LAUNCH(gn_apply_part_kernel<false>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
                        (long)emb_stride, out, HW, C, G, act, sp);
   return check_launch("gn_apply_from_partials");
 }
@@ -346,17 +346,17 @@ int mf_maxabs_rows_f32(const float* x, float* partial, float* bound, int N, int6
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * N * (double)per_row);
   const int slots = mf_maxabs_rows_slots(per_row);
-  hipLaunchKernelGGL(maxabs_kernel, dim3(slots / 4, N), dim3(256), 0, s, x, partial, (long)(per_row / 4));
+  MF_LAUNCH(maxabs_kernel, dim3(slots / 4, N), dim3(256), 0, s, x, partial, (long)(per_row / 4));
   int rc = check_launch("maxabs_rows");
   if (rc) return rc;
-  hipLaunchKernelGGL(bound_finalize_kernel, dim3(N), dim3(64), 0, s, partial, bound, slots);
+  MF_LAUNCH(bound_finalize_kernel, dim3(N), dim3(64), 0, s, partial, bound, slots);
   return check_launch("bound_finalize");
 }
 
 int mf_bound_finalize_f32(const float* partial, float* bound, int N, int slots, void* stream) {
   MF_REQUIRE(partial && bound && N > 0 && slots > 0, MF_EINVAL, "bound_finalize: bad args");
   ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 4.0 * N * slots);
-  hipLaunchKernelGGL(bound_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partial, bound, slots);
+  MF_LAUNCH(bound_finalize_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, partial, bound, slots);
   return check_launch("bound_finalize");
 }
 
@@ -368,7 +368,7 @@ int mf_gn_finalize_f32(const double* partial, int parts, float* stats, int N, in
   hipStream_t s = (hipStream_t)stream;
   const int NG = N * G;
   ProfScope ps(MF_FAM_GN_STATS, s, 0, 16.0 * NG * parts);
-  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, partial, stats, NG, G, parts, (double)HW * (C / G), eps);
+  MF_LAUNCH(gn_stats_final_kernel, dim3((NG * 16 + 255) / 256), dim3(256), 0, s, partial, stats, NG, G, parts, (double)HW * (C / G), eps);
   return check_launch("gn_finalize");
 }
 
@@ -380,8 +380,8 @@ int mf_gn_stats_partial_f32(const float* x, double* partial, int N, int HW, int 
   MF_REQUIRE(lds <= 64 * 1024, MF_EUNSUPPORTED, "gn_stats_partial: C=%d too wide", C);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_GN_STATS, s, 3.0 * N * HW * C, 4.0 * N * (double)HW * C);
-  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(stats_chunks(HW), N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
-                     (float*)nullptr);
+  MF_LAUNCH(gn_partial_kernel<false>, dim3(stats_chunks(HW), N, slices), dim3(kStatsThreads), lds, s, x, partial, HW, C, G, 1, 0L, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr);
   return check_launch("gn_stats_partial");
 }
 

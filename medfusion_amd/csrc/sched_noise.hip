@@ -143,13 +143,13 @@ int mf_sched_step_f32(const MfSchedArgs* a, void* stream) {
   ProfScope ps(MF_FAM_SCHED, s, 12.0 * a->n, 4.0 * a->n * 6);
   long blocks = (a->n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sched_step_kernel, dim3((int)blocks), dim3(256), 0, s, *a);
+  MF_LAUNCH(sched_step_kernel, dim3((int)blocks), dim3(256), 0, s, *a);
   return check_launch("sched_step");
 }
 
 int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int32_t step, float* out, int n, void* stream) {
   MF_REQUIRE(table && out && n > 0, MF_EINVAL, "broadcast_from_table: bad args");
-  hipLaunchKernelGGL(broadcast_from_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, step_dev, step, out, n);
+  MF_LAUNCH(broadcast_from_table_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, step_dev, step, out, n);
   return check_launch("broadcast_from_table");
 }
 
@@ -159,14 +159,14 @@ int mf_gather_step_rows_f32(const float* table, const int64_t* cols, const int32
   const long total = (long)B * row_len;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gather_step_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, table, reinterpret_cast<const long*>(cols), step_dev,
+  MF_LAUNCH(gather_step_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, table, reinterpret_cast<const long*>(cols), step_dev,
                      step, ncol, (long)row_len, out, total);
   return check_launch("gather_step_rows");
 }
 
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream) {
   MF_REQUIRE(counter, MF_EINVAL, "counter_add: null");
-  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, inc);
+  MF_LAUNCH(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, inc);
   return check_launch("counter_add");
 }
 
@@ -181,7 +181,7 @@ int mf_philox_normal_f32(float* out, uint64_t seed, int32_t draw_base, int32_t d
   ProfScope ps(MF_FAM_NOISE, s, 100.0 * total, 16.0 * total);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(philox_normal_kernel, dim3((int)blocks), dim3(256), 0, s, out, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), draw_base,
+  MF_LAUNCH(philox_normal_kernel, dim3((int)blocks), dim3(256), 0, s, out, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32), draw_base,
                      draw_stride, step_dev, step, (long)sample_offset, B, quads);
   return check_launch("philox_normal");
 }

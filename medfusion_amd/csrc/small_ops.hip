@@ -183,7 +183,7 @@ int mf_linear_f32(const float* x, int64_t x_stride, const float* w, const float*
   MF_REQUIRE((In & 3) != 0 || (((uintptr_t)w & 15) == 0), MF_EINVAL, "linear: weight must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_LINEAR, s, 2.0 * B * In * (double)Out, 4.0 * ((double)In * Out + (double)B * (In + Out)));
-  hipLaunchKernelGGL(linear_kernel, dim3((Out + 4 * kLinOutPerWave - 1) / (4 * kLinOutPerWave)), dim3(256), lds, s, x, (long)x_stride, w, bias, y, (long)y_stride, B, In, Out, act_in,
+  MF_LAUNCH(linear_kernel, dim3((Out + 4 * kLinOutPerWave - 1) / (4 * kLinOutPerWave)), dim3(256), lds, s, x, (long)x_stride, w, bias, y, (long)y_stride, B, In, Out, act_in,
                      act_out, accumulate);
   return check_launch("linear");
 }
@@ -196,7 +196,7 @@ int mf_sinusoidal_f32(const float* t, const float* freqs, float* out, int B, int
   const float coef = (float)(log((double)max_period) / ((double)half - (double)shift));
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * B * dim);
-  hipLaunchKernelGGL(sinusoidal_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, t, freqs, out, B, dim, coef, flip);
+  MF_LAUNCH(sinusoidal_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, t, freqs, out, B, dim, coef, flip);
   return check_launch("sinusoidal");
 }
 
@@ -204,7 +204,7 @@ int mf_embedding_add_f32(const float* table, const int64_t* idx, float* io, int 
   MF_REQUIRE(table && idx && io && B > 0 && D > 0 && num_rows > 0, MF_EINVAL, "embedding_add: bad args");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 0, 12.0 * B * D);
-  hipLaunchKernelGGL(embedding_add_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, table, idx, io, B, D, num_rows);
+  MF_LAUNCH(embedding_add_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, table, idx, io, B, D, num_rows);
   return check_launch("embedding_add");
 }
 
@@ -212,7 +212,7 @@ static int transpose_planes(const float* x, float* y, int N, int R, int Cc, hipS
   MF_REQUIRE(x && y && N > 0 && R > 0 && Cc > 0, MF_EINVAL, "%s: bad args", what);
   MF_REQUIRE(N <= 65535, MF_EUNSUPPORTED, "%s: N too large", what);
   ProfScope ps(MF_FAM_MISC, s, 0, 8.0 * N * (double)R * Cc);
-  hipLaunchKernelGGL(transpose_planes_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, N), dim3(32, 8), 0, s, x, y, R, Cc);
+  MF_LAUNCH(transpose_planes_kernel, dim3((Cc + 31) / 32, (R + 31) / 32, N), dim3(32, 8), 0, s, x, y, R, Cc);
   return check_launch(what);
 }
 
@@ -229,7 +229,7 @@ int mf_add_f32(const float* a, const float* b, float* out, int64_t n, void* stre
   ProfScope ps(MF_FAM_MISC, s, (double)n, 12.0 * n);
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(add_kernel, dim3((int)blocks), dim3(256), 0, s, a, b, out, (long)n);
+  MF_LAUNCH(add_kernel, dim3((int)blocks), dim3(256), 0, s, a, b, out, (long)n);
   return check_launch("add");
 }
 
@@ -238,7 +238,7 @@ int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float*
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)N * C * HW;
   ProfScope ps(MF_FAM_MISC, s, 4.0 * total, 16.0 * total);
-  hipLaunchKernelGGL(diag_gaussian_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, moments, noise, z, N, C, HW);
+  MF_LAUNCH(diag_gaussian_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, moments, noise, z, N, C, HW);
   return check_launch("diag_gaussian");
 }
 
@@ -246,7 +246,7 @@ int mf_layernorm_f32(const float* x, const float* gamma, const float* beta, floa
   MF_REQUIRE(x && gamma && beta && out && rows > 0 && C > 0, MF_EINVAL, "layernorm: bad args");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 8.0 * rows * C, 8.0 * rows * C);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, eps);
+  MF_LAUNCH(layernorm_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, s, x, gamma, beta, out, (long)rows, C, eps);
   return check_launch("layernorm");
 }
 
@@ -257,7 +257,7 @@ int mf_geglu_f32(const float* h, float* out, int64_t rows, int C, void* stream) 
   ProfScope ps(MF_FAM_MISC, s, 10.0 * total, 12.0 * total);
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(geglu_kernel, dim3((int)blocks), dim3(256), 0, s, h, out, (long)rows, C);
+  MF_LAUNCH(geglu_kernel, dim3((int)blocks), dim3(256), 0, s, h, out, (long)rows, C);
   return check_launch("geglu");
 }
 

@@ -571,6 +571,14 @@ def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> tor
 
 
 # ----------------------------------------------------------------------------- launch timing
+_PROF_ACTIVE = [False]
+
+
+def prof_active() -> bool:
+    """launch timing is on (the command-list loop steps aside: replayed launches would not be timed)"""
+    return _PROF_ACTIVE[0]
+
+
 class prof:
     """with prof() as p: ...; p.table() -> {family: (ms, launches, algorithmic flops, bytes, executed flops)}"""
 
@@ -578,11 +586,13 @@ class prof:
         lib = L.load()
         lib.mf_prof_reset()
         lib.mf_prof_enable(1)
+        _PROF_ACTIVE[0] = True
         return self
 
     def __exit__(self, *exc):
         torch.cuda.synchronize()
         L.load().mf_prof_enable(0)
+        _PROF_ACTIVE[0] = False
         return False
 
     @staticmethod

@@ -91,6 +91,11 @@ _SIGS = {
     "mf_prof_query2": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mf_prof_family_name": (C.c_char_p, [_I]),
     "mf_mfma_rate_probe_f16": (_I, [c_fp, c_fp, _I, _I, C.POINTER(C.c_double), c_fp]),
+    "mf_cmdlist_begin": (_I, []),
+    "mf_cmdlist_end": (_I, [C.POINTER(C.c_void_p)]),
+    "mf_cmdlist_count": (_I, [c_fp]),
+    "mf_cmdlist_replay": (_I, [c_fp, _I, c_fp]),
+    "mf_cmdlist_free": (_I, [c_fp]),
 }
 
 _lib = None

@@ -11,6 +11,8 @@ rows across GPUs with shard-invariant noise.  Training (`_step`) i
 from __future__ import annotations
 
 import copy
+import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -63,6 +65,9 @@ class DiffusionPipeline(nn.Module):
         self.clip_x0 = clip_x0
         self.batch_cfg = True  # classifier-free guidance as one 2B-row UNet call (same arithmetic per row)
         self.hoist_embeddings = True  # denoise(): time/label/local embeddings of all iterations evaluated once, before the loop
+        self._cmd_pools = {}          # device index -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from
+        self._graph_streams = {}      # device index -> the one side stream graph captures run on
+        self.last_cmdlist_launches = 0
         self.use_ema = use_ema
         if use_ema:
             self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
@@ -146,15 +151,15 @@ class DiffusionPipeline(nn.Module):
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
     def denoise(self, x_t, steps=None, condition=None, use_ddim=True, noise: Optional[NoiseSource] = None, trace=None, decode=True, use_graph=None,
-                **kwargs):
+                loop: Optional[str] = None, **kwargs):
         """diffusion_pipeline.py:278-310.  kwargs: guidance_scale, un_cond, cold_diffusion (forwarded to forward()
         by the reference); `eta` raises like the reference's forward() would (Q2)."""
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
         with torch.cuda.device(x_t.device):   # (see sample())
-            return self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs)
+            return self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **kwargs)
 
-    def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, **kwargs):
+    def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **kwargs):
         K.SyncWords.reset(x_t.device)   # (the split-K counters of the convolutions: zero by invariant, re-zeroed once per loop for robustness)
         if "eta" in kwargs:
             raise TypeError("forward() got an unexpected keyword argument 'eta'")
@@ -169,15 +174,30 @@ class DiffusionPipeline(nn.Module):
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
         if use_graph and trace is not None:
             raise ValueError("use_graph=True cannot record a trace (the captured step is replayed, nothing returns to the host)")
-        if use_graph is None:
-            # Replaying the iteration as a captured hipGraph removes the host's 2.0 ms of launch work per iteration but dispatches every
-            # kernel node ~1 us later than a stream-ordered launch (profiles/r02_host_enqueue_time.txt, ms per 150 iterations, graph vs
-            # eager: B=1 at 8x8 227 vs 301, B=4 at 32x32 275 vs 272, B=8 359 vs 341, B=16 521 vs 493): worth it only while the host
-            # is the bottleneck.
-            from .noise import PhiloxDeviceNoise
-            rows = x_t.shape[0] * (2 if (condition is not None and guidance_scale != 1.0) else 1)
-            use_graph = (trace is None and not cold_diffusion and (noise is None or isinstance(noise, PhiloxDeviceNoise))
-                         and rows * x_t.shape[-1] * x_t.shape[-2] <= 2 * 32 * 32 and (steps is None or steps >= 8))
+        # How the loop body reaches the device (all three give the same bits: test_hipgraph_captured_step_equals_eager,
+        # test_cmdlist_replay_equals_eager):
+        #   "cmdlist" (default where possible): iteration 0 eager, iteration 1 recorded by the library while it runs (mf_cmdlist_begin/end),
+        #             every further iteration re-issued from C (mf_cmdlist_replay): stream-ordered launches at ~1 us of host time each
+        #             instead of 2.0 ms of Python -> ctypes work per iteration (profiles/r03_host_enqueue_time.txt);
+        #   "graph":  the iteration as ONE captured hipGraph (use_graph=True; BASELINE configs[3] names it): no host work either, but every
+        #             kernel node dispatches ~1 us later than a stream-ordered launch -- slower than the eager loop from B ~ 6 on;
+        #   "eager":  the Python loop (needed for a trace, a host noise source, cold diffusion).
+        from .noise import PhiloxDeviceNoise
+        replayable = (trace is None and not cold_diffusion and (noise is None or isinstance(noise, PhiloxDeviceNoise)) and (steps is None or steps >= 4))
+        if loop is not None and loop not in ("cmdlist", "graph", "eager"):
+            raise ValueError(f"loop={loop!r}: 'cmdlist', 'graph' or 'eager'")
+        # precedence: loop= argument, use_graph= (True: graph, False: eager), MEDFUSION_LOOP in the environment, then the default
+        mode = loop or ("graph" if use_graph else "eager" if use_graph is False else os.environ.get("MEDFUSION_LOOP", ""))
+        explicit = loop is not None or use_graph is not None
+        if mode not in ("cmdlist", "graph", "eager"):
+            mode = "cmdlist"
+        if mode == "cmdlist" and (not replayable or K.prof_active()):
+            if loop == "cmdlist" and not replayable:
+                raise ValueError("loop='cmdlist' replays recorded launches: no trace, no host noise source, no cold diffusion, >= 4 iterations")
+            mode = "eager"
+        if mode == "graph" and not replayable and not explicit:
+            mode = "eager"
+        use_graph = mode == "graph"
         sch = self.noise_scheduler
         dev = x_t.device
         B = x_t.shape[0]
@@ -210,8 +230,8 @@ class DiffusionPipeline(nn.Module):
             if decode and self.latent_embedder is not None:
                 x_t = self.latent_embedder.decode(x_t)
             return x_t
-        if use_graph:
-            self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective)
+        if mode in ("graph", "cmdlist"):
+            self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=(mode == "cmdlist"))
         else:
             t_all = torch.tensor(rev, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, B).contiguous()  # t.expand(B) per iteration (Q7)
             n_post = torch.empty_like(x_t)
@@ -252,8 +272,9 @@ class DiffusionPipeline(nn.Module):
         tab = est.precompute_embeddings(t_steps, classes=used if has_c else None)
         return (tab, est.embedding_columns(condition if has_c else None, B, dev, tab), est.embedding_columns(un_cond if has_c else None, B, dev, tab))
 
-    def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective):
-        """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]).  Everything the
+    def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=False):
+        """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]) -- or, cmdlist=True, recorded by the
+        library while it runs once and re-issued from C (mf_cmdlist_*: the native command list of the loop body).  Everything the
         reference reads on the host each iteration (t, alphas_cumprod[t], the t==0 test, the RNG state) is indexed by a
         DEVICE step counter: `t` is broadcast from a device table, the scheduler scalars come from the MfSchedStep table,
         the Philox draw index is draw_base + stride*step, and the graph advances the counter itself.  The last DDIM
@@ -287,9 +308,7 @@ class DiffusionPipeline(nn.Module):
             K.counter_add(step_dev, 1)
             return pred  # keep alive until the end of capture
 
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        def first_iteration():
             # Q11: with self-conditioning the first call sees self_cond=None -> run it eagerly in that form
             if self.use_self_conditioning:
                 K.broadcast_from_table(t_table, step_dev, t_cur)
@@ -304,6 +323,41 @@ class DiffusionPipeline(nn.Module):
                 K.counter_add(step_dev, 1)
             else:
                 body()  # eager warm-up iteration 0: sizes every workspace / packs weights on THIS stream
+
+        if cmdlist:
+            # the native command list: iteration 0 eager (weights packed, workspaces sized, kernel attributes set), iteration 1 recorded
+            # while it runs -- inside a private memory pool, so that every buffer the recorded launches point at stays reserved, what a
+            # graph capture's pool does -- and iterations 2 .. re-issued from C on the same stream
+            lib = L.load()
+            cur = K.stream(dev.index)
+            first_iteration()
+            if len(rev) > 1:
+                pool = self._cmd_pools.get(dev.index)
+                if pool is None:
+                    pool = self._cmd_pools[dev.index] = torch.cuda.MemPool()
+                handle = ctypes.c_void_p()
+                with torch.cuda.use_mem_pool(pool, device=dev):
+                    L.check(lib.mf_cmdlist_begin(), "mf_cmdlist_begin")
+                    try:
+                        keep = body()
+                    finally:
+                        L.check(lib.mf_cmdlist_end(ctypes.byref(handle)), "mf_cmdlist_end")
+                try:
+                    self.last_cmdlist_launches = lib.mf_cmdlist_count(handle)
+                    if len(rev) > 2:
+                        L.check(lib.mf_cmdlist_replay(handle, len(rev) - 2, cur), "mf_cmdlist_replay")
+                finally:
+                    lib.mf_cmdlist_free(handle)    # (the kernarg bytes were copied at every launch)
+                del keep
+            noise.draw_index = base + stride * len(rev)
+            return
+        side = self._graph_streams.get(dev.index)      # ONE capture stream per device (per-stream workspaces / split-K counters stay bounded)
+        if side is None:
+            side = self._graph_streams[dev.index] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            K.SyncWords.reset(dev)    # (the counters of THIS stream: _denoise reset those of the caller's stream)
+            first_iteration()
             done = 1
             if len(rev) > done:
                 graph = torch.cuda.CUDAGraph()

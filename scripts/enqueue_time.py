@@ -13,12 +13,16 @@ from medfusion_amd import published as P
 
 dev = torch.device("cuda:0")
 pipe = P.build_published_pipeline(dev, num_classes=None)
-for rep, (b, lat, graph) in enumerate([(16, 32, False), (16, 32, False), (16, 32, True), (16, 32, True), (1, 8, False), (1, 8, True), (4, 32, False), (4, 32, True),
-                                       (8, 32, False), (8, 32, True)]):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    img = pipe.sample(b, (8, lat, lat), steps=150, use_ddim=True, noise=M.PhiloxDeviceNoise(rep), use_graph=graph)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print(f"rep {rep} B={b} latent {lat} graph={graph}: enqueued after {1e3 * (t1 - t0):.1f} ms, device idle after {1e3 * (t2 - t0):.1f} ms", flush=True)
+pipe.sample(16, (8, 32, 32), steps=150, use_ddim=True, noise=M.PhiloxDeviceNoise(0))   # warm-up
+rep = 0
+for b, lat in ((16, 32), (8, 32), (4, 32), (1, 8)):
+    for loop in ("eager", "graph", "cmdlist", "cmdlist"):
+        rep += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        img = pipe.sample(b, (8, lat, lat), steps=150, use_ddim=True, noise=M.PhiloxDeviceNoise(rep), loop=loop)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"B={b} latent {lat} loop={loop:8s}: enqueued after {1e3 * (t1 - t0):6.1f} ms ({1e3 * (t1 - t0) / 150:.2f} ms / iteration), device idle after "
+              f"{1e3 * (t2 - t0):6.1f} ms", flush=True)

@@ -183,9 +183,11 @@ def test_cfg4_graph_replay_at_full_size(dev, conv_precision):
     100 iterations equal the eager loop bit for bit; the full 1000-iteration replay finishes finite (1001 noise draws)."""
     pipe = P.build_published_pipeline(dev, num_classes=None)
     kw = dict(use_ddim=False, decode=False)
-    eager = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), **kw)
+    eager = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), loop="eager", **kw)
     graph = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), use_graph=True, **kw)
     assert torch.equal(eager, graph)
+    listed = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), loop="cmdlist", **kw)    # the default loop of sample()
+    assert torch.equal(eager, listed) and pipe.last_cmdlist_launches > 100
     if conv_precision == 5:
         src = M.PhiloxDeviceNoise(4)
         img = pipe.sample(8, (8, 32, 32), steps=None, use_ddim=False, noise=src, use_graph=True)

@@ -292,9 +292,18 @@ def test_hipgraph_captured_step_equals_eager(dev, use_ddim, cond):
     kw = dict(steps=9, use_ddim=use_ddim)
     if cond:
         kw.update(condition=torch.tensor([2, 0, 1, 1], device=dev), guidance_scale=4.0)
-    eager = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), **kw)
+    eager = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), loop="eager", **kw)
     graph = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), use_graph=True, **kw)
     assert torch.equal(eager, graph)
+    # the native command list of the loop body (iteration 1 recorded by the library, the rest re-issued from C): the same bits, and it is
+    # what sample() does by default
+    pipe.last_cmdlist_launches = 0
+    listed = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), loop="cmdlist", **kw)
+    assert torch.equal(eager, listed) and pipe.last_cmdlist_launches > 20
+    pipe.last_cmdlist_launches = 0
+    assert torch.equal(eager, pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), **kw)) and pipe.last_cmdlist_launches > 20
+    with pytest.raises(ValueError, match="cmdlist"):
+        pipe.sample(2, (8, 8, 8), noise=oracle_noise(1), loop="cmdlist", steps=5)
     again = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), use_graph=True, **kw)
     assert torch.equal(graph, again)
     with pytest.raises(RuntimeError, match="Philox"):
