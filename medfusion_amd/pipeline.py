@@ -17,11 +17,42 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.utils._python_dispatch
 
 from . import kernels as K
 from . import lib as L
 from .noise import NoiseSource, default_noise
 from .scheduler import GaussianNoiseScheduler
+
+
+class _PureLaunchGuard(torch.utils._python_dispatch.TorchDispatchMode):
+    """Active while the library records one loop iteration: notes every ATen operator that touches device memory other than allocation and
+    metadata -- such work is not a launch of the library, so a replay of the recorded list would miss it."""
+    ALLOWED = {"aten::empty", "aten::empty_like", "aten::empty_strided", "aten::new_empty", "aten::new_empty_strided", "aten::view", "aten::_unsafe_view",
+               "aten::reshape", "aten::_reshape_alias", "aten::slice", "aten::select", "aten::as_strided", "aten::expand", "aten::unsqueeze", "aten::squeeze",
+               "aten::t", "aten::transpose", "aten::permute", "aten::detach", "aten::alias", "aten::unbind", "aten::split", "aten::narrow",
+               "aten::lift_fresh", "aten::is_pinned", "aten::stride", "aten::size", "aten::sym_size", "aten::sym_stride", "aten::sym_numel",
+               "aten::sym_storage_offset", "aten::is_contiguous", "aten::contiguous", "aten::_to_copy", "aten::resize_"}
+
+    def __init__(self):
+        super().__init__()
+        self.foreign = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = func._schema.name
+        if name not in self.ALLOWED or name in ("aten::contiguous", "aten::_to_copy"):
+            def on_device(v):
+                if isinstance(v, torch.Tensor):
+                    return v.is_cuda
+                if isinstance(v, (list, tuple)):
+                    return any(on_device(u) for u in v)
+                return False
+            touches = on_device(out) or on_device(args) or on_device(list((kwargs or {}).values()))
+            # contiguous / _to_copy of a device tensor launch a copy kernel only when they really copy
+            if touches and not (name == "aten::contiguous" and out is (args[0] if args else None)):
+                self.foreign.append(name)
+        return out
 
 
 class EMAModel(nn.Module):
@@ -67,7 +98,8 @@ class DiffusionPipeline(nn.Module):
         self.hoist_embeddings = True  # denoise(): time/label/local embeddings of all iterations evaluated once, before the loop
         self._cmd_pools = {}          # device index -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from
         self._graph_streams = {}      # device index -> the one side stream graph captures run on
-        self.last_cmdlist_launches = 0
+        self.last_cmdlist_launches = 0          # launches in the list the last command-list loop replayed (0: it ran eagerly)
+        self.last_cmdlist_foreign_ops = []      # ATen operators that put device work into the recorded iteration (replay refused)
         self.use_ema = use_ema
         if use_ema:
             self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
@@ -88,7 +120,8 @@ class DiffusionPipeline(nn.Module):
 
     def _predict(self, x_t, t, condition, self_cond, guidance_scale, un_cond, emb=None):
         """UNet call(s) of forward :240-253.  Returns (pred, pred_uncond|None, pred_var|None).
-        emb = (table, i, cols_cond, cols_uncond): the loop's precomputed embeddings (UNet.precompute_embeddings), or None."""
+        emb = (table, i, cols_cond, cols_uncond, cols_uncond ++ cols_cond): the loop's precomputed embeddings
+        (UNet.precompute_embeddings), or None."""
         est = self._estimator()
         cfg = (condition is not None) and (guidance_scale != 1.0)
         ec = (lambda cols: None) if emb is None else (lambda cols: est.step_embeddings(emb[0], emb[1], cols))
@@ -99,7 +132,7 @@ class DiffusionPipeline(nn.Module):
             if self.batch_cfg and not self.use_self_conditioning:
                 # both passes of diffusion_pipeline.py:242-243 as ONE UNet call over 2B rows (rows are independent):
                 # rows [0,B) = un-guided (condition = un_cond, possibly None), rows [B,2B) = guided.
-                pred2 = est.forward_cfg_pair(x_t, t, condition, un_cond, emb_cache=None if emb is None else ec(torch.cat([emb[3], emb[2]])))
+                pred2 = est.forward_cfg_pair(x_t, t, condition, un_cond, emb_cache=None if emb is None else ec(emb[4]))
                 B = x_t.shape[0]
                 return pred2[B:], pred2[:B], None
             pred_uncond, _ = est(x_t, t, condition=un_cond, self_cond=self_cond, emb_cache=None if emb is None else ec(emb[3]))  # un-guided pass FIRST (Q6)
@@ -242,7 +275,7 @@ class DiffusionPipeline(nn.Module):
             emb_tab = self._hoisted_embeddings(est, t_all[:, 0].contiguous(), condition, un_cond, B, dev)
             for i in range(len(rev)):
                 pred, pred_uncond, pred_var = self._predict(x_t, t_all[i], condition, self_cond, guidance_scale, un_cond,
-                                                            emb=None if emb_tab is None else (emb_tab[0], i, emb_tab[1], emb_tab[2]))
+                                                            emb=None if emb_tab is None else (emb_tab[0], i, emb_tab[1], emb_tab[2], emb_tab[3]))
                 noise.draw(tuple(x_t.shape), out=n_post)          # gaussian_scheduler.py:99 -- drawn on every iteration (Q3)
                 ddim = recs[i].mode == 1
                 if ddim:
@@ -270,7 +303,8 @@ class DiffusionPipeline(nn.Module):
             if has_c and lab is not None:
                 used.update(int(v) for v in lab.reshape(-1).tolist())
         tab = est.precompute_embeddings(t_steps, classes=used if has_c else None)
-        return (tab, est.embedding_columns(condition if has_c else None, B, dev, tab), est.embedding_columns(un_cond if has_c else None, B, dev, tab))
+        cc, cu = est.embedding_columns(condition if has_c else None, B, dev, tab), est.embedding_columns(un_cond if has_c else None, B, dev, tab)
+        return (tab, cc, cu, torch.cat([cu, cc]))   # (the last: columns of the 2B-row classifier-free-guidance pair, un-guided rows first)
 
     def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=False):
         """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]) -- or, cmdlist=True, recorded by the
@@ -293,7 +327,7 @@ class DiffusionPipeline(nn.Module):
         clip, g = int(bool(self.clip_x0)), float(guidance_scale)
 
         emb_tab = self._hoisted_embeddings(self._estimator(), t_table, condition, un_cond, B, dev)
-        emb = None if emb_tab is None else (emb_tab[0], step_dev, emb_tab[1], emb_tab[2])   # rows of iteration *step_dev, gathered on the device
+        emb = None if emb_tab is None else (emb_tab[0], step_dev, emb_tab[1], emb_tab[2], emb_tab[3])   # rows of iteration *step_dev, gathered on the device
 
         def body():
             K.broadcast_from_table(t_table, step_dev, t_cur)
@@ -336,7 +370,8 @@ class DiffusionPipeline(nn.Module):
                 if pool is None:
                     pool = self._cmd_pools[dev.index] = torch.cuda.MemPool()
                 handle = ctypes.c_void_p()
-                with torch.cuda.use_mem_pool(pool, device=dev):
+                guard = _PureLaunchGuard()
+                with torch.cuda.use_mem_pool(pool, device=dev), guard:
                     L.check(lib.mf_cmdlist_begin(), "mf_cmdlist_begin")
                     try:
                         keep = body()
@@ -344,7 +379,14 @@ class DiffusionPipeline(nn.Module):
                         L.check(lib.mf_cmdlist_end(ctypes.byref(handle)), "mf_cmdlist_end")
                 try:
                     self.last_cmdlist_launches = lib.mf_cmdlist_count(handle)
-                    if len(rev) > 2:
+                    self.last_cmdlist_foreign_ops = sorted(set(guard.foreign))
+                    if guard.foreign:
+                        # torch itself put device work into the iteration (self-conditioning, an attention variant, ...): the recorded list
+                        # is not the whole iteration -- drop it and run the remaining iterations through Python (same bits, host-bound)
+                        self.last_cmdlist_launches = 0
+                        for _ in range(2, len(rev)):
+                            body()
+                    elif len(rev) > 2:
                         L.check(lib.mf_cmdlist_replay(handle, len(rev) - 2, cur), "mf_cmdlist_replay")
                 finally:
                     lib.mf_cmdlist_free(handle)    # (the kernarg bytes were copied at every launch)

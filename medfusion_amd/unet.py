@@ -263,7 +263,9 @@ class UNet(nn.Module):
         """Classifier-free-guidance pair in one pass: returns y [2B,...] with rows [0,B) = forward(x_t, t, un_cond) and
         rows [B,2B) = forward(x_t, t, condition).  Per-row arithmetic is the same as two separate calls."""
         B = x_t.shape[0]
-        x2 = torch.cat([x_t, x_t], dim=0)            # plumbing: 2 x 8192*B floats
+        x2 = torch.empty((2 * B, *x_t.shape[1:]), dtype=x_t.dtype, device=x_t.device)   # plumbing: 2 x 8192*B floats, through the library
+        K.rows_axpby(x_t, out=x2[:B])                  # (launches of the library only inside the loop body: the command-list loop
+        K.rows_axpby(x_t, out=x2[B:])                  #  re-issues exactly those -- pipeline.py)
         if emb_cache is not None:
             h, _ = self.features(x2, None, None, None, emb_cache=emb_cache)
             return self.outc(h)
