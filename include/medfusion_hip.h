@@ -282,6 +282,12 @@ int mf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, vo
  * moments NCHW [N][2C][HW] -> z [N][C][HW] */
 int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float* z, int N, int C, int HW, void* stream);
 
+/* learnable_interpolation=False (ABI 210): BasicDown = nn.AvgPool2d(k, stride, get_padding(k, stride)) (conv_blocks.py:57-63; count_include_pad
+ * like torch's default: the divisor counts the padding), BasicUp = F.interpolate(nearest-exact) to twice the size (conv_blocks.py:128-130).
+ * NHWC fp32, C % 4 == 0. */
+int mf_avgpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream);
+int mf_upsample_nearest2x_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+
 /* Image egress on the device: NCHW float -> NHWC uint8.
  * mode 0: scripts/helpers/sample_dataset.py:44-53  clip(-1,1) -> (x+1)/2*255 -> astype(uint8)   (bit-exact vs numpy)
  * mode 1: scripts/sample.py:49-51 + torchvision save_image(normalize=True, scale_each=True): (x+1)/2, clamp(0,1), per-image

@@ -341,31 +341,48 @@ class UnetBasicBlock(_EmbBlock):
 
 
 class BasicDown(nn.Module):
-    """conv_blocks.py:28-70 (learnable: 3x3 stride-s conv, key `down_op.*`)."""
+    """conv_blocks.py:28-70.  Learnable: 3x3 stride-s conv (key `down_op.*`); learnable_interpolation=False: nn.AvgPool2d(k, stride,
+    get_padding(k, stride)), no parameters, the channel count stays.  `use_res` (PixelUnshuffle skip, :54-55) is never set by the reference's
+    models (DownBlock :397 and unet2.py:107-114 pass / default False) and is not built."""
 
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=3, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
-        if not learnable_interpolation or use_res:
-            raise NotImplementedError("BasicDown: only the learnable strided conv is on the HIP path")
-        self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
+        if use_res:
+            raise NotImplementedError("BasicDown(use_res=True): the PixelUnshuffle skip is unreachable from the reference's models and not built")
+        self.learnable = bool(learnable_interpolation)
+        if self.learnable:
+            self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
+        else:
+            self.k, self.stride, self.pad = kernel_size, stride, monai_padding(kernel_size, stride)
 
     def forward(self, x, emb=None):
-        return self.down_op(x, measure_out=f16x2_mode())
+        if self.learnable:
+            return self.down_op(x, measure_out=f16x2_mode())
+        if isinstance(x, (tuple, list)):
+            raise RuntimeError("BasicDown(learnable_interpolation=False) takes one tensor")
+        return K.avgpool2d(x, self.k, self.stride, self.pad)
 
 
 class BasicUp(nn.Module):
-    """conv_blocks.py:72-131: nearest-exact x2 then 3x3 conv, fused into one gather (key `up_op.*`)."""
+    """conv_blocks.py:72-131: nearest-exact x2 then 3x3 conv, fused into one gather (key `up_op.*`); learnable_interpolation=False: the plain
+    nearest-exact resize (:128-130), no parameters.  `use_res` (PixelShuffle skip, :114-115): see BasicDown."""
 
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=2, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
-        if not learnable_interpolation or use_res:
-            raise NotImplementedError("BasicUp: only the learnable resize-conv is on the HIP path")
+        if use_res:
+            raise NotImplementedError("BasicUp(use_res=True): the PixelShuffle skip is unreachable from the reference's models and not built")
         if (kernel_size, stride) != (2, 2):
             raise NotImplementedError("BasicUp: only x2 upsampling (kernel_size=stride=2) is supported")
-        self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
+        self.learnable = bool(learnable_interpolation)
+        if self.learnable:
+            self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
 
     def forward(self, x, emb=None):
-        return self.up_op(x, measure_out=f16x2_mode())
+        if self.learnable:
+            return self.up_op(x, measure_out=f16x2_mode())
+        if isinstance(x, (tuple, list)):
+            raise RuntimeError("BasicUp(learnable_interpolation=False) takes one tensor")
+        return K.upsample_nearest2x(x)
 
 
 class SequentialEmb(nn.Sequential):
@@ -515,6 +532,7 @@ class UpBlock(nn.Module):
         super().__init__()
         enable_up = stride != 1
         skip_out = out_channels if learnable_interpolation and enable_up else in_channels + skip_channels
+        self.learnable_interpolation = bool(learnable_interpolation)
         self.up_op = BasicUp(spatial_dims, in_channels, out_channels, upsample_kernel_size, stride, learnable_interpolation) if enable_up else nn.Identity()
         self.attention = Attention(spatial_dims, skip_out, skip_out, 8, skip_out // 8, norm_name, dropout, emb_channels, 1, use_attention)
         Blk = UnetResBlock if use_res_block else UnetBasicBlock
@@ -523,6 +541,11 @@ class UpBlock(nn.Module):
     def forward(self, x_enc, x_skip=None, emb=None):
         x = self.up_op(x_enc)
         if x_skip is not None:
-            x = K.add(x, x_skip, out=x)
+            if self.learnable_interpolation:     # conv_blocks.py:516-519: equal channel counts -> sum, else concatenate
+                x = K.add(x, x_skip, out=x)
+            else:
+                if hasattr(self.attention, "attention"):
+                    raise NotImplementedError("UpBlock(learnable_interpolation=False) with a skip AND attention")
+                return self.conv_block((x, x_skip), None)   # the concat is fused into the consuming convolutions
         x = self.attention(x, emb)
         return self.conv_block(x, None)

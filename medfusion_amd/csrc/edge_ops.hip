@@ -98,7 +98,71 @@ __global__ void image_u8_normalized_kernel(const float* __restrict__ x, const fl
 
 }  // namespace
 
+// nn.AvgPool2d(k, stride, pad) with count_include_pad (torch's default), NHWC: the window is clipped to the PADDED extent for the divisor and
+// to the image for the sum, summed row by row like ATen's scalar loop, then ONE division (conv_blocks.py:57-63, learnable_interpolation=False)
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4, int Ho, int Wo,
+                                                            int k, int stride, int pad) {
+#pragma clang fp contract(off)
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    int hs = oy * stride - pad, ws = ox * stride - pad;
+    int he = min(hs + k, H + pad), we = min(ws + k, W + pad);
+    const float pool = (float)((he - hs) * (we - ws));
+    hs = max(hs, 0); ws = max(ws, 0); he = min(he, H); we = min(we, W);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int iy = hs; iy < he; ++iy)
+      for (int ix = ws; ix < we; ++ix) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (((long)n * H + iy) * W + ix) * (C4 * 4L) + c4 * 4);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(s.x / pool, s.y / pool, s.z / pool, s.w / pool);
+  }
+}
+
+// F.interpolate(x, scale 2, mode="nearest-exact") on NHWC: out[oy][ox] = in[oy / 2][ox / 2] (conv_blocks.py:128-130)
+__global__ __launch_bounds__(256) void upsample_nearest2_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4) {
+  const long total = (long)N * (2 * H) * (2 * W) * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % (2 * W));
+    r /= 2 * W;
+    const int oy = (int)(r % (2 * H)), n = (int)(r / (2 * H));
+    *reinterpret_cast<float4*>(y + i * 4) = *reinterpret_cast<const float4*>(x + (((long)n * H + (oy >> 1)) * W + (ox >> 1)) * (C4 * 4L) + c4 * 4);
+  }
+}
+
 extern "C" {
+
+int mf_avgpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {
+  MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MF_EINVAL, "avgpool2d: bad args (C %% 4 == 0)");
+  MF_REQUIRE(k >= 1 && stride >= 1 && pad >= 0 && 2 * pad <= k, MF_EINVAL, "avgpool2d: kernel %d stride %d pad %d", k, stride, pad);
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  MF_REQUIRE(Ho > 0 && Wo > 0, MF_EINVAL, "avgpool2d: empty output");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  ProfScope ps(MF_FAM_MISC, s, (double)k * k * total * 4, 4.0 * ((double)N * H * W * C + (double)total * 4));
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MF_LAUNCH(avgpool_nhwc_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, N, H, W, C / 4, Ho, Wo, k, stride, pad);
+  return check_launch("avgpool2d");
+}
+
+int mf_upsample_nearest2x_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MF_EINVAL, "upsample_nearest2x: bad args (C %% 4 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * 4 * H * W * (C / 4);
+  ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * 5 * (double)N * H * W * C);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MF_LAUNCH(upsample_nearest2_nhwc_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, N, H, W, C / 4);
+  return check_launch("upsample_nearest2x");
+}
 
 int mf_rows_axpby_f32(const float* x, const float* y, const float* a, const float* c, const float* d, float* out, int B, int64_t per_row,
                       int do_clamp, float lo, float hi, void* stream) {

@@ -561,6 +561,25 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def avgpool2d(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+    """nn.AvgPool2d(k, stride, pad) on NHWC (count_include_pad like torch's default)"""
+    _gpu(x)
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_avgpool2d_nhwc_f32(x.contiguous().data_ptr(), out.data_ptr(), n, h, w, c, k, stride, pad, stream()), "mf_avgpool2d_nhwc_f32")
+    return out
+
+
+def upsample_nearest2x(x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(scale 2, nearest-exact) on NHWC"""
+    _gpu(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_upsample_nearest2x_nhwc_f32(x.contiguous().data_ptr(), out.data_ptr(), n, h, w, c, stream()), "mf_upsample_nearest2x_nhwc_f32")
+    return out
+
+
 def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     _gpu(moments_nchw, noise)
     n, c2, h, w = moments_nchw.shape

@@ -100,6 +100,8 @@ class DiffusionPipeline(nn.Module):
         self._graph_streams = {}      # device index -> the one side stream graph captures run on
         self.last_cmdlist_launches = 0          # launches in the list the last command-list loop replayed (0: it ran eagerly)
         self.last_cmdlist_foreign_ops = []      # ATen operators that put device work into the recorded iteration (replay refused)
+        self.time_cmdlist = False               # measurement aid: time the host side of one replayed iteration (costs a device sync)
+        self.last_cmdlist_host_ms = None
         self.use_ema = use_ema
         if use_ema:
             self.ema_model = EMAModel(self.noise_estimator, **ema_kwargs)
@@ -387,7 +389,15 @@ class DiffusionPipeline(nn.Module):
                         for _ in range(2, len(rev)):
                             body()
                     elif len(rev) > 2:
-                        L.check(lib.mf_cmdlist_replay(handle, len(rev) - 2, cur), "mf_cmdlist_replay")
+                        left = len(rev) - 2
+                        if self.time_cmdlist and left > 1:   # measurement aid (scripts/enqueue_time.py): the host cost of ONE replayed
+                            import time                       # iteration with an empty queue in front of it
+                            torch.cuda.synchronize(dev)
+                            t0 = time.perf_counter()
+                            L.check(lib.mf_cmdlist_replay(handle, 1, cur), "mf_cmdlist_replay")
+                            self.last_cmdlist_host_ms = (time.perf_counter() - t0) * 1e3
+                            left -= 1
+                        L.check(lib.mf_cmdlist_replay(handle, left, cur), "mf_cmdlist_replay")
                 finally:
                     lib.mf_cmdlist_free(handle)    # (the kernarg bytes were copied at every launch)
                 del keep

@@ -193,6 +193,31 @@ def case_attention():
 
 
 @torch.no_grad()
+def case_nonlearnable():
+    """learnable_interpolation=False (conv_blocks.py:57-63 AvgPool, :128-130 plain nearest-exact): the reference's own outputs, own fixtures
+    (blocks.npz / unet_tiny_*.npz of the earlier rounds stay byte-identical)"""
+    out = {}
+    ref, ora = RC.BasicDown(2, 32, 32, 3, 2, learnable_interpolation=False), R.BasicDown(32, 32, 3, 2, learnable_interpolation=False)
+    for tag, shape in (("even", (2, 32, 10, 12)), ("odd", (2, 32, 9, 11))):
+        xd = S.synth_input(f"nl_down_{tag}", shape)
+        check_equal(f"nl_down_{tag}", ref(xd), ora(xd))
+        out.update({f"down_{tag}_x": xd, f"down_{tag}_y": ref(xd)})
+    ref, ora = RC.BasicUp(2, 32, 32, 2, 2, learnable_interpolation=False), R.BasicUp(32, 32, 2, 2, learnable_interpolation=False)
+    xu = S.synth_input("nl_up_x", (2, 32, 5, 6))
+    check_equal("nl_up", ref(xu), ora(xu))
+    out.update(up_x=xu, up_y=ref(xu))
+    save("blocks_nonlearnable", **out)
+    kw = R.tiny_unet_kwargs(2, "none", learnable_interpolation=False)
+    ref, ora = RefUNet(**ref_unet_kwargs(kw)).eval(), R.UNet(**kw).eval()
+    synth_pair(ref, ora, "unet_nonlearnable.")
+    x = S.synth_input("unet_x", (2, 8, 8, 8))
+    t, c = torch.tensor([37, 37]), torch.tensor([0, 1])
+    (ya, _), (yb, _) = ref(x, t, c), ora(x, t, c)
+    check_equal("unet_nonlearnable", ya, yb)
+    save("unet_tiny_nonlearnable", x=x, t=t, cond=c, y=ya)
+
+
+@torch.no_grad()
 def case_unets():
     x = S.synth_input("unet_x", (2, 8, 8, 8))
     t = torch.tensor([37, 37])
@@ -351,7 +376,7 @@ def case_cfg1_published():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    cases = [case_scheduler, case_embedders, case_blocks, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
+    cases = [case_scheduler, case_embedders, case_blocks, case_nonlearnable, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
     for fn in cases:
         if only and fn.__name__ not in only:
             continue

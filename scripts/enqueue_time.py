@@ -26,3 +26,10 @@ for b, lat in ((16, 32), (8, 32), (4, 32), (1, 8)):
         t2 = time.perf_counter()
         print(f"B={b} latent {lat} loop={loop:8s}: enqueued after {1e3 * (t1 - t0):6.1f} ms ({1e3 * (t1 - t0) / 150:.2f} ms / iteration), device idle after "
               f"{1e3 * (t2 - t0):6.1f} ms", flush=True)
+    # the host side of ONE replayed iteration with nothing queued in front of it (a launch call blocks once the hardware queue is full,
+    # so "enqueued after" above is the DEVICE's pace whenever the device is the slower side)
+    pipe.time_cmdlist = True
+    pipe.sample(b, (8, lat, lat), steps=20, use_ddim=True, noise=M.PhiloxDeviceNoise(99), loop="cmdlist")
+    pipe.time_cmdlist = False
+    print(f"B={b} latent {lat}: command list of {pipe.last_cmdlist_launches} launches, host time of one replayed iteration {pipe.last_cmdlist_host_ms:.3f} ms "
+          f"({1e3 * pipe.last_cmdlist_host_ms / max(1, pipe.last_cmdlist_launches):.2f} us per launch)", flush=True)

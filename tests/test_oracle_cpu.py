@@ -123,6 +123,22 @@ def test_unet_tiny(tag):
     assert relerr(yu, T(g["y_uncond"])) <= TOL
 
 
+@torch.no_grad()
+def test_nonlearnable_down_up_and_unet():
+    """learnable_interpolation=False (conv_blocks.py:57-63 AvgPool, :128-130 nearest-exact) against what the REFERENCE computed
+    (oracle/gen_golden.py::case_nonlearnable)"""
+    g = gold("blocks_nonlearnable")
+    d, u = R.BasicDown(32, 32, 3, 2, learnable_interpolation=False), R.BasicUp(32, 32, 2, 2, learnable_interpolation=False)
+    for tag in ("even", "odd"):
+        assert torch.equal(d(T(g[f"down_{tag}_x"])), T(g[f"down_{tag}_y"]))
+    assert torch.equal(u(T(g["up_x"])), T(g["up_y"]))
+    g = gold("unet_tiny_nonlearnable")
+    m = R.UNet(**R.tiny_unet_kwargs(2, "none", learnable_interpolation=False)).eval()
+    S.synth_state_dict(m, "unet_nonlearnable.")
+    y, _ = m(T(g["x"]), T(g["t"]), T(g["cond"]))
+    assert relerr(y, T(g["y"])) <= TOL
+
+
 REFTEST_KW = dict(in_ch=3, out_ch=3, spatial_dims=2, hid_chs=[32, 64, 128, 256], kernel_sizes=[1, 3, 3, 3], strides=[1, 2, 2, 2],
                   time_embedder=R.TimeEmbbeding, time_embedder_kwargs={"emb_dim": 64}, cond_embedder=R.LabelEmbedder,
                   cond_embedder_kwargs={"emb_dim": 64, "num_classes": 2}, deep_supervision=True, use_res_block=True, use_attention="linear")

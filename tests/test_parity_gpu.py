@@ -81,6 +81,26 @@ def test_blocks_golden(dev):
     assert relerr(nchw(u.to(dev)(nhwc(T(g["up_x"]), dev))), T(g["up_y"])) < TOL
 
 
+def test_nonlearnable_down_up_golden(dev):
+    """learnable_interpolation=False: AvgPool (bit-exact: same window order, one division) and nearest-exact x2 (a copy) against the
+    reference's outputs; a tiny UNet built that way against the reference's"""
+    from medfusion_amd import blocks as B
+    g = gold("blocks_nonlearnable")
+    d, u = B.BasicDown(2, 32, 32, 3, 2, learnable_interpolation=False), B.BasicUp(2, 32, 32, 2, 2, learnable_interpolation=False)
+    assert len(list(d.parameters())) == 0 and len(list(u.parameters())) == 0
+    for tag in ("even", "odd"):
+        assert torch.equal(nchw(d(nhwc(T(g[f"down_{tag}_x"]), dev))), T(g[f"down_{tag}_y"])), tag
+    assert torch.equal(nchw(u(nhwc(T(g["up_x"]), dev))), T(g["up_y"]))
+    with pytest.raises(NotImplementedError):
+        B.BasicDown(2, 32, 128, 3, 2, use_res=True)
+    g = gold("unet_tiny_nonlearnable")
+    m = M.UNet(**to_product_kwargs(R.tiny_unet_kwargs(2, "none", learnable_interpolation=False)))
+    S.synth_state_dict(m, "unet_nonlearnable.")
+    m.to(dev)
+    y, _ = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["cond"]).to(dev))
+    assert relerr(y, T(g["y"])) < TOL
+
+
 def test_attention_golden(dev):
     from medfusion_amd import blocks as B
     g = gold("attention")
