@@ -27,9 +27,17 @@ __device__ __forceinline__ int scale_exp_of(float bound) {
 }
 __device__ __forceinline__ float exp2i(int s) { return __uint_as_float((unsigned)(127 + s) << 23); }  // 2^s, -126 <= s <= 127
 
+// A finite value that exceeds its bound (it never does when the bound is one) saturates at the fp16 range; NaN and +-Inf are NOT clamped:
+// they go through the conversions as NaN / Inf (hi = NaN or Inf, lo' = NaN), the matrix cores carry them on, and the convolution's output
+// is non-finite like the fp32 reference's would be -- a clamp (fminf / fmaxf return the other operand for NaN) would turn them into a
+// finite, silently wrong number.
+__device__ __forceinline__ float clamp_f16_range(float a) {
+  const float c = __builtin_fminf(__builtin_fmaxf(a, -kF16Max), kF16Max);
+  return __builtin_fabsf(a) <= 3.4028234663852886e38f ? c : a;   // (false for NaN and Inf)
+}
 __device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
-  a = __builtin_fminf(__builtin_fmaxf(a, -kF16Max), kF16Max);
-  b = __builtin_fminf(__builtin_fmaxf(b, -kF16Max), kF16Max);
+  a = clamp_f16_range(a);
+  b = clamp_f16_range(b);
   const _Float16 ha = (_Float16)a, hb = (_Float16)b;                             // round to nearest even
   const float ra = (a - (float)ha) * kLoScale, rb = (b - (float)hb) * kLoScale;  // both operations exact
   const sf_f16x2 h = {ha, hb}, l = {(_Float16)ra, (_Float16)rb};

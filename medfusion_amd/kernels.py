@@ -132,6 +132,24 @@ def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
 # fp16-pair convolution can MEASURE the bound of its output (measure_out=True); a consumer that finds neither runs the stand-alone
 # passes (max |t| per sample, then the split) once and caches the result on the tensor.  Every wrapper that writes INTO an existing
 # tensor (`out=`) drops stale mirrors first.
+def _stamp(t: torch.Tensor) -> None:
+    """remember the tensor's version counter next to its mirrors: a torch in-place op on `t` bumps `_version`, and stale() sees it (writes
+    through this library go by raw pointer and do not: every wrapper that writes INTO an existing tensor calls drop_split itself)"""
+    t._mf_ver = t._version
+
+
+def stale(t: torch.Tensor) -> bool:
+    return getattr(t, "_mf_ver", None) is not None and t._mf_ver != t._version
+
+
+def _fresh(t: torch.Tensor, name: str):
+    """attribute `name` of t (a mirror), or None -- dropping every mirror first when a torch in-place op has touched t since they were made"""
+    if stale(t):
+        drop_split(t)
+        t._mf_ver = None
+    return getattr(t, name, None)
+
+
 def drop_split(t: Optional[torch.Tensor]) -> None:
     if t is not None:
         if getattr(t, "_mf_split", None) is not None:
@@ -157,15 +175,16 @@ def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def bound_of(x: torch.Tensor) -> torch.Tensor:
-    b = getattr(x, "_mf_bound", None)
+    b = _fresh(x, "_mf_bound")
     if b is None:
-        sl = getattr(x, "_mf_slots", None)
+        sl = _fresh(x, "_mf_slots")
         if sl is not None:   # per-(tile, wave) maxima the producing convolution left: one wave per sample reduces them
             b = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
             L.check(L.load().mf_bound_finalize_f32(sl.data_ptr(), b.data_ptr(), sl.shape[0], sl.shape[1], stream()), "mf_bound_finalize_f32")
         else:
             b = maxabs_rows(x)
         x._mf_bound = b
+        _stamp(x)
     return b
 
 
@@ -184,10 +203,11 @@ def split_f16x2(x: torch.Tensor, bound: Optional[torch.Tensor] = None) -> torch.
 
 
 def split_of(x: torch.Tensor) -> torch.Tensor:
-    s = getattr(x, "_mf_split", None)
+    s = _fresh(x, "_mf_split")
     if s is None:
         s = split_f16x2(x, bound_of(x))
         x._mf_split = s
+        _stamp(x)
     return s
 
 
@@ -254,6 +274,7 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     L.check(rc, "mf_conv2d_f16x2")
     if slots:   # per-(tile, wave) maxima: reduced to the bound of each sample by the first consumer that asks (bound_of), or inside the
         out._mf_slots = yb   # GroupNorm-apply pass that takes this tensor as its residual (without slots a consumer measures on demand)
+        _stamp(out)
     return (out, partial) if gn_groups else out
 
 
@@ -377,12 +398,12 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
     if split:  # (before `out` may alias x or the residual: their bounds describe the values this pass READS)
         xb = bound_of(x) if (stats is None and part is None) else None
         if residual is not None:
-            if part is not None and getattr(residual, "_mf_bound", None) is None and getattr(residual, "_mf_slots", None) is not None:
+            if part is not None and _fresh(residual, "_mf_bound") is None and _fresh(residual, "_mf_slots") is not None:
                 rslots = residual._mf_slots
             else:
                 rb = bound_of(residual)
         if emb is not None:
-            eb = getattr(emb, "_mf_bound", None)
+            eb = _fresh(emb, "_mf_bound")
             if eb is None:
                 eb = maxabs_rows(emb.contiguous())
     if out is None:
@@ -404,6 +425,7 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
         L.check(rc, "mf_gn_apply_split_f32")
     if split:
         out._mf_split, out._mf_bound = outs, ob
+        _stamp(out)
     return out
 
 
@@ -416,6 +438,8 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], act_i
     assert w.shape[1] == inn and x.stride(1) == 1 and w.is_contiguous()
     if out is None:
         out = torch.empty((b, o), dtype=torch.float32, device=x.device)
+    else:
+        drop_split(out)
     rc = L.load().mf_linear_f32(x.data_ptr(), x.stride(0), w.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0), b, inn, o, int(act_in),
                                 int(act_out), int(accumulate), stream())
     L.check(rc, "mf_linear_f32")
@@ -435,6 +459,7 @@ def sinusoidal(t: torch.Tensor, dim: int, max_period: float = 10000.0, shift: fl
 def embedding_add(table: torch.Tensor, idx: torch.Tensor, io: torch.Tensor) -> torch.Tensor:
     _gpu(table, idx, io)
     idx = idx.to(torch.int64).contiguous()
+    drop_split(io)
     L.check(L.load().mf_embedding_add_f32(table.data_ptr(), idx.data_ptr(), io.data_ptr(), io.shape[0], io.shape[1], table.shape[0], stream()),
             "mf_embedding_add_f32")
     return io
@@ -446,6 +471,7 @@ def philox_normal(out: torch.Tensor, seed: int, draw: int, sample_offset: int = 
     _gpu(out, step_dev)
     b = out.shape[0]
     per = out.numel() // b
+    drop_split(out)
     rc = L.load().mf_philox_normal_f32(out.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, draw, draw_stride, _ptr(step_dev), 0, sample_offset, b, per, stream())
     L.check(rc, "mf_philox_normal_f32")
     return out
@@ -461,6 +487,8 @@ def rows_axpby(x: torch.Tensor, a: Optional[torch.Tensor] = None, y: Optional[to
     b = x.shape[0]
     if out is None:
         out = torch.empty_like(x)
+    else:
+        drop_split(out)
     lo, hi = clamp if clamp is not None else (0.0, 0.0)
     rc = L.load().mf_rows_axpby_f32(x.data_ptr(), _ptr(y), _ptr(a), _ptr(c), _ptr(d), out.data_ptr(), b, x.numel() // b, int(clamp is not None),
                                     float(lo), float(hi), stream())
@@ -479,7 +507,10 @@ def image_to_uint8(x_nchw: torch.Tensor, normalize_each: bool = False) -> torch.
     return out
 
 
-def sched_step(args: L.MfSchedArgs) -> None:
+def sched_step(args: L.MfSchedArgs, outputs=()) -> None:
+    """`outputs`: the tensors the step writes (x_t, x0, ...): the call goes by raw pointers, their fp16-pair mirrors (if any) are stale after it"""
+    for t in outputs:
+        drop_split(t)
     L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
 
 
@@ -498,6 +529,7 @@ def gather_step_rows(table: torch.Tensor, step, cols: torch.Tensor) -> torch.Ten
 
 def broadcast_from_table(table: torch.Tensor, step_dev: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     _gpu(table, step_dev, out)
+    drop_split(out)
     L.check(L.load().mf_broadcast_from_table_f32(table.data_ptr(), step_dev.data_ptr(), 0, out.data_ptr(), out.numel(), stream()), "mf_broadcast_from_table_f32")
     return out
 

@@ -179,7 +179,7 @@ class DiffusionPipeline(nn.Module):
                           None if pred_var is None else pred_var.data_ptr(), noise.data_ptr(), None, 0, prior.data_ptr(), x0.data_ptr(),
                           xT.data_ptr(), table.data_ptr(), None, 0, 0 if self.estimator_objective == "x_T" else 1, int(bool(self.clip_x0)),
                           float(guidance_scale), x_t.numel())
-        K.sched_step(a)
+        K.sched_step(a, outputs=(prior, x0, xT))
         self_cond = x0 if self.estimator_objective == "x_T" else xT
         return prior, x0, xT, self_cond
 
@@ -286,7 +286,7 @@ class DiffusionPipeline(nn.Module):
                                   None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if ddim else None, 0,
                                   x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), None, i, objective, int(bool(self.clip_x0)),
                                   float(guidance_scale), x_t.numel())
-                K.sched_step(a)
+                K.sched_step(a, outputs=(x_t, x0))
                 self_cond = x0 if self.use_self_conditioning else None  # only None-ness matters downstream (Q11)
                 if trace is not None:
                     trace.append((x0.clone(), x_t.clone()))
@@ -340,7 +340,7 @@ class DiffusionPipeline(nn.Module):
             a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
                               None if pred_var is None else pred_var.data_ptr(), n_post.data_ptr(), n_ddim.data_ptr() if use_ddim else None, 0,
                               x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(), step_dev.data_ptr(), 0, objective, clip, g, x_t.numel())
-            K.sched_step(a)
+            K.sched_step(a, outputs=(x_t, x0))
             K.counter_add(step_dev, 1)
             return pred  # keep alive until the end of capture
 
@@ -355,7 +355,7 @@ class DiffusionPipeline(nn.Module):
                 a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pu is None else pu.data_ptr(), None if pv is None else pv.data_ptr(),
                                   n_post.data_ptr(), n_ddim.data_ptr() if use_ddim else None, 0, x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(),
                                   step_dev.data_ptr(), 0, objective, clip, g, x_t.numel())
-                K.sched_step(a)
+                K.sched_step(a, outputs=(x_t, x0))
                 K.counter_add(step_dev, 1)
             else:
                 body()  # eager warm-up iteration 0: sizes every workspace / packs weights on THIS stream

@@ -665,6 +665,41 @@ def test_conv_f16_single_term(dev, case):
                 assert torch.equal(y, first), (case, tile)
 
 
+def test_f16x2_operands_carry_nan_and_inf_and_never_go_stale(dev):
+    """(a) the fp16-pair split must not turn NaN / Inf into a finite number (a clamp with fminf / fmaxf does): a non-finite
+    activation gives a non-finite convolution output, like the fp32 reference's; (b) the mirrors cached on a tensor are dropped by EVERY
+    writer -- a torch in-place op (version counter) and every wrapper of this library that writes into an existing tensor."""
+    from medfusion_amd import kernels as K
+    n, h, w, c, co = 2, 8, 8, 64, 64
+    x = _rand("nan_x", (n, h, w, c)).to(dev)
+    wt = K.split_weight_f16x2(K.pack_conv_weight(_rand("nan_w", (co, c, 3, 3), 0.05).to(dev)))
+    d = K.make_conv_desc(n, h, w, c, 0, co, 3, 1, 1, 0, precision=5)
+    y0 = K.conv2d_f16x2(x, wt, None, d)
+    assert bool(torch.isfinite(y0).all())
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        xb = x.clone()
+        xb[1, 3, 4, 7] = bad
+        s = K.split_f16x2(xb, xb.abs().nan_to_num(posinf=1e30).amax(dim=(1, 2, 3)))
+        raw = s.view(torch.int32)[1, 3, 4, 0:8].view(torch.float16)       # the 8-channel group [hi x 8 | lo x 8] holding channel 7
+        assert not bool(torch.isfinite(raw[7])), (bad, raw)
+        yb = K.conv2d_f16x2(xb, wt, None, d)
+        assert not bool(torch.isfinite(yb[1]).all()), bad                 # the sample with the bad value
+        assert torch.equal(yb[0], y0[0]), bad                             # the other sample is untouched
+    # (b) stale mirrors
+    x1 = x.clone()
+    s1, b1 = K.split_of(x1), K.bound_of(x1)
+    x1.mul_(3.0)                                                          # torch in-place: the version counter moves
+    assert K.stale(x1)
+    s2, b2 = K.split_of(x1), K.bound_of(x1)
+    assert torch.equal(b2, x1.abs().amax(dim=(1, 2, 3))) and torch.equal(s2, K.split_f16x2(x1, b2)) and not torch.equal(b1, b2)
+    for write in (lambda t: K.rows_axpby(x, out=t), lambda t: K.philox_normal(t, 1, 0), lambda t: K.add(x, x, out=t)):
+        t = x.clone()
+        K.split_of(t)
+        write(t)
+        assert getattr(t, "_mf_split", None) is None and getattr(t, "_mf_bound", None) is None
+        assert torch.equal(K.split_of(t), K.split_f16x2(t, t.abs().amax(dim=(1, 2, 3))))
+
+
 def test_gn_apply_split_mirror(dev):
     """gn_apply(split=True) writes the fp16-pair mirror of exactly what it writes in fp32, scaled by the bound it derives and
     publishes: bconst + bound(residual) + bound(embedding row) >= max |out|"""
