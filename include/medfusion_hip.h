@@ -168,6 +168,15 @@ int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int 
                                   const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split,
                                   const float* res_bound, const float* res_bound_slots, int res_nslots, const float* emb_bound, float bconst,
                                   float* out_bound, int N, int HW, int C, int G, int act, void* stream);
+/* The same pass for tensors that exist ONLY as fp16 pairs between two convolutions (ABI 210; conv_blocks.py:236-240 where the block output
+ * feeds convolutions and residual adds alone): `out` may be NULL -- only the pair form out_split is written, 12 instead of 16 bytes per
+ * element -- and the residual may be given as pairs (`residual_pairs`, scaled by `res_bound`; `residual` must then be NULL): it is read back
+ * as hi + lo/2048 times its scale, i.e. the fp32 value with its last significand bit cleared at most (<= 2^-23 relative, the order of the
+ * rounding of the add itself). */
+int mf_gn_apply_from_partials_pairs_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
+                                        const float* residual, const void* residual_pairs, const float* emb, int64_t emb_stride, float* out,
+                                        void* out_split, const float* res_bound, const float* res_bound_slots, int res_nslots,
+                                        const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);
 /* bound[n] = max |x[n][:]| over per_row elements: the measured operand bound of tensors no producer bounded analytically (network
  * input convolutions, embedding rows).  Two launches, no atomics: every wave stores the max of its share into its own slot of
  * `partial` (N * mf_maxabs_rows_slots(per_row) floats of caller scratch), then one wave per row reduces the slots.

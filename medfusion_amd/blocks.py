@@ -87,6 +87,7 @@ class _Packed:
         return self._w3
 
 
+PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"   # (A/B switch of the pairs-only apply output)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
 #   5 (default) fp32 through PAIRS of fp16: 23-bit operands with a per-sample power-of-two scale, three product terms on the fp16 matrix
@@ -167,6 +168,7 @@ class Conv(nn.Module):
                 if r is not None:
                     return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
+            K._need_f32(x1, x2)
         key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, prec)
         ent = self._descs.get(key)
         cout = self.out_ch if rows is None else rows.stop - rows.start
@@ -242,12 +244,12 @@ class BasicBlock(nn.Module):
             self.norm = _norm(norm_name, out_channels)
         self.has_act = act_name is not None
 
-    def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC):
+    def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out_fp32=True):
         has_norm = hasattr(self, "norm")
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
-            return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride)
+            return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride, out_fp32)
         y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         if not (self.has_act or residual is not None or emb is not None):
             return y
@@ -261,12 +263,13 @@ def _basicblock_conv_and_stats(self, x, in_layout=L.LAYOUT_NHWC):
     return self.conv(x, in_layout=in_layout, gn_groups=self.norm.num_groups, gn_eps=self.norm.eps)
 
 
-def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0):
+def _basicblock_finish(self, y_stats, residual=None, emb=None, emb_stride=0, out_fp32=True):
     y, stats = y_stats
     nm = self.norm
     split = f16x2_mode()
     bc = nm.bound_const(y.shape[1] * y.shape[2] * (y.shape[3] // nm.num_groups)) if split else 0.0
-    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=split, bconst=bc)
+    return K.gn_apply(y, stats, nm.weight, nm.bias, nm.num_groups, int(self.has_act), residual, emb, emb_stride, out=y, split=split, bconst=bc,
+                      out_fp32=out_fp32)
 
 
 BasicBlock.conv_and_stats = _basicblock_conv_and_stats
@@ -283,13 +286,20 @@ class BasicResBlock(nn.Module):
         self.basic_block = BasicBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, act_name, dropout, zero_conv)
         self.conv_res = Conv(in_channels, out_channels, 1, stride, monai_padding(1, stride)) if in_channels != out_channels else nn.Identity()
 
-    def forward(self, x: Act, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC):
+    def forward(self, x: Act, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_fp32=True):
+        """out_fp32=False: the caller promises that the block's output is read by fp16-pair convolutions and residual adds only"""
         if isinstance(self.conv_res, nn.Identity):
             if isinstance(x, (tuple, list)) or in_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("identity residual needs a single NHWC input")
-            return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+            return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
         res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
-        return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout)
+        return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
+
+    def reads_pairs_only(self) -> bool:
+        """can this block take an input that exists as fp16 pairs only?  Its convolutions must be on the fp16-pair kernel (its residual add
+        reads pairs anyway)"""
+        convs = [self.basic_block.conv] + ([] if isinstance(self.conv_res, nn.Identity) else [self.conv_res])
+        return f16x2_mode() and hasattr(self.basic_block, "norm") and all(c.in_ch % 32 == 0 and c.out_ch % 64 == 0 for c in convs)
 
 
 class _EmbBlock(nn.Module):
@@ -317,7 +327,11 @@ class _EmbBlock(nn.Module):
             e = emb if (emb is not None and i < last) else None
             es = e.stride(0) if e is not None else 0
             if isinstance(blk, BasicResBlock):
-                x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
+                # the output of every block but the last is read by the NEXT block alone: its convolutions (fp16 pairs) and its residual
+                # add -- the fp32 form need not be written when that block can read pairs (12 instead of 16 bytes per element)
+                nxt = self.block_seq[i + 1] if i + 1 < n else None
+                x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC,
+                        out_fp32=not (PAIRS_ONLY_BETWEEN_BLOCKS and nxt is not None and nxt.reads_pairs_only()))
             else:
                 x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
         return x

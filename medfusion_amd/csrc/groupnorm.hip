@@ -50,7 +50,20 @@ struct GnSplit {
   float* out_bound;         // [N] written by the pass
   const float* res_slots;   // (from-partials pass) the residual's bound still as the [N][res_nslots] slot maxima its convolution wrote, or null
   int res_nslots;
+  const void* res_pairs;    // (from-partials pass) the residual exists ONLY in its fp16-pair form (scaled by res_bound): read from there
 };
+
+// 4 consecutive channels starting at element index e (a multiple of 4) of a tensor stored as fp16 pairs, back as fp32: hi + lo' / 2048 is
+// exact in fp32 (23 significant bits), the power of two `sc` (2^s of the sample) too: the value is the original fp32 number with its last
+// significand bit cleared at most (split_f16.h)
+__device__ __forceinline__ float4 load_pairs4(const void* pairs, long e, float sc) {
+  const uint2* g = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pairs) + (e >> 3) * 32 + ((e >> 2) & 1) * 8);
+  const uint2 h = g[0], l = g[2];   // [hi x 8] then [lo' x 8]: 16 bytes apart
+  const sf_f16x2 h0 = __builtin_bit_cast(sf_f16x2, h.x), h1 = __builtin_bit_cast(sf_f16x2, h.y), l0 = __builtin_bit_cast(sf_f16x2, l.x),
+                 l1 = __builtin_bit_cast(sf_f16x2, l.y);
+  return make_float4(((float)h0[0] + (float)l0[0] * kLoInv) * sc, ((float)h0[1] + (float)l0[1] * kLoInv) * sc,
+                     ((float)h1[0] + (float)l1[0] * kLoInv) * sc, ((float)h1[1] + (float)l1[1] * kLoInv) * sc);
+}
 
 // out = act(gn(x)*gamma + beta) + residual + emb[n][c]
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -156,9 +169,12 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
   const long per4 = (long)HW * C4, base = (long)n * per4, step = (long)gridDim.x * 256;
   long j = (long)blockIdx.x * 256 + tid;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f), r = v;
+  const bool res_p = SPLIT && sp.res_pairs != nullptr;                                    // the residual lives as fp16 pairs only
+  const float rsc = res_p ? exp2i(scale_exp_of(sp.res_bound[n])) : 1.f;
   if (j < per4) {
     v = *reinterpret_cast<const float4*>(x + (base + j) * 4);
-    if (residual) r = *reinterpret_cast<const float4*>(residual + (base + j) * 4);
+    if (res_p) r = load_pairs4(sp.res_pairs, (base + j) * 4, rsc);
+    else if (residual) r = *reinterpret_cast<const float4*>(residual + (base + j) * 4);
   }
   if (tid < G) {
     double s = 0, q = 0;
@@ -191,7 +207,8 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
     float4 vn = v, rn = r;
     if (jn < per4) {
       vn = *reinterpret_cast<const float4*>(x + (base + jn) * 4);
-      if (residual) rn = *reinterpret_cast<const float4*>(residual + (base + jn) * 4);
+      if (res_p) rn = load_pairs4(sp.res_pairs, (base + jn) * 4, rsc);
+      else if (residual) rn = *reinterpret_cast<const float4*>(residual + (base + jn) * 4);
     }
     const int c = (int)(j % C4) * 4;
     float e[4] = {v.x, v.y, v.z, v.w};
@@ -203,12 +220,12 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
       if (act == 1) t = swish_acc(t);
       e[k] = t;
     }
-    if (residual) { e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w; }
+    if (residual || res_p) { e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w; }
     if (emb) {
       const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
       e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
     }
-    *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);
+    if (!SPLIT || out) *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);   // (null: pairs only)
     if (SPLIT) store_split4(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);
     v = vn; r = rn; j = jn;
   }
@@ -291,7 +308,7 @@ int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma
   if (out_split) {
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound, nullptr, 0};
+    const GnSplit sp{out_split, x_bound, res_bound, emb_bound, bconst, out_bound, nullptr, 0, nullptr};
     MF_LAUNCH(gn_apply_split_kernel, dim3((int)blocks), dim3(256), 0, s, x, stats, gamma, beta, residual, emb, (long)emb_stride, out, total4, HW,
                        C, G > 0 ? G : 1, act, sp);
     return check_launch("gn_apply_split");
@@ -307,7 +324,17 @@ int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int 
                                   const float* residual, const float* emb, int64_t emb_stride, float* out, void* out_split, const float* res_bound,
                                   const float* res_bound_slots, int res_nslots, const float* emb_bound, float bconst, float* out_bound, int N, int HW,
                                   int C, int G, int act, void* stream) {
-  MF_REQUIRE(x && out && gn_partial && parts > 0 && N > 0 && N <= 65535 && HW > 0 && C > 0, MF_EINVAL, "gn_apply_from_partials: bad args");
+  return mf_gn_apply_from_partials_pairs_f32(x, gn_partial, parts, eps, gamma, beta, residual, nullptr, emb, emb_stride, out, out_split, res_bound,
+                                             res_bound_slots, res_nslots, emb_bound, bconst, out_bound, N, HW, C, G, act, stream);
+}
+
+int mf_gn_apply_from_partials_pairs_f32(const float* x, const double* gn_partial, int parts, float eps, const float* gamma, const float* beta,
+                                        const float* residual, const void* residual_pairs, const float* emb, int64_t emb_stride, float* out,
+                                        void* out_split, const float* res_bound, const float* res_bound_slots, int res_nslots,
+                                        const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream) {
+  MF_REQUIRE(x && (out || out_split) && gn_partial && parts > 0 && N > 0 && N <= 65535 && HW > 0 && C > 0, MF_EINVAL, "gn_apply_from_partials: bad args");
+  MF_REQUIRE(!residual_pairs || (!residual && out_split && res_bound), MF_EINVAL,
+             "gn_apply_from_partials: a residual given as fp16 pairs needs out_split and the res_bound that scaled it, and excludes the fp32 residual");
   MF_REQUIRE(G > 0 && G <= 256 && C % G == 0 && C % 4 == 0, MF_EUNSUPPORTED, "gn_apply_from_partials: C=%d G=%d (C %% 4 == 0, C %% G == 0, G <= 256)", C, G);
   MF_REQUIRE(!out_split || (C % 8 == 0 && out_bound), MF_EUNSUPPORTED, "gn_apply_from_partials: the fp16-pair output needs C %% 8 == 0 and out_bound");
   MF_REQUIRE(!out_split || !residual || res_bound || (res_bound_slots && res_nslots > 0), MF_EINVAL,
@@ -318,11 +345,11 @@ int mf_gn_apply_from_partials_f32(const float* x, const double* gn_partial, int 
   hipStream_t s = (hipStream_t)stream;
   const long per4 = (long)HW * (C / 4);
   const double nelem = (double)N * HW * C;
-  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (2 + (residual ? 1 : 0) + (out_split ? 1 : 0)));
+  ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (1 + (out ? 1 : 0) + (residual || residual_pairs ? 1 : 0) + (out_split ? 1 : 0)));
   long bps = (per4 + 255) / 256;
   const long cap = (256 * 8 + N - 1) / N;   // ~8 blocks per CU over the whole launch
   if (bps > cap) bps = cap;
-  const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots};
+  const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots, residual_pairs};
   const double count = (double)HW * (C / G);
   if (out_split)
     MF_LAUNCH(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,

