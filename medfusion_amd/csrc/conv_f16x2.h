@@ -395,226 +395,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     st = st == NST - 1 ? 0 : st + 1;
   }
 
-  // ---- epilogue.  D[cout][pixel]: lane holds pixel (lane & 31) and couts (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of each 32 x 32 block.
-  // All DMA has landed (the last iterations wait vmcnt(0)); the stages are dead once every wave has left the loop.
-  MFC2_WAIT_LGKM0();
-  __builtin_amdgcn_s_barrier();
-  if constexpr (MFC2_HZ_ON(0)) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-  if (p.tree) {   // ---- split-K met inside the launch (see ConvP2)
-    // the accumulators become the values of this K slice, (main + cross / 2048) x 2^(operand scales); `accx` is cleared so that the
-    // epilogue below, which forms the same expression for the other launches, reproduces them (f_out = 1 there)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      MFC2_PIXEL_EXPS(i)
-      const float f_out = exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accm[i][j][r] = (accm[i][j][r] + accx[i][j][r] * kLoInv) * f_out; accx[i][j][r] = 0.f; }
-    }
-    constexpr int SLOT = BM * BN;                       // floats per hand-off slot; inside a slot: [wave][i][j][q][lane][4]
-    const int tile = tile_n * p.tiles_m + tile_m;
-    float* region = p.handoff + (long)tile * (2L * (p.splitk - 1)) * SLOT;
-    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(region, 0, (unsigned)(2 * (p.splitk - 1)) * (unsigned)SLOT * 4u, 0x00020000);
-    unsigned* cnt = p.sync + (long)tile * (p.splitk - 1);
-    unsigned* flag = reinterpret_cast<unsigned*>(smem);   // (the pipeline stages are dead)
-    const unsigned lane_off = (unsigned)((wave * TM * TN * 4) * 64 + lane) * 16u;
-    int lbase = 0;
-    for (int span = 1; span < p.splitk; span <<= 1) {
-      if constexpr (MFC2_HZ_ON(4)) asm volatile("s_nop 15" ::: "memory");
-      const int lv = __builtin_ctz(span);
-      const int side = (kz >> lv) & 1, pair = kz >> (lv + 1);
-      const unsigned mine = (unsigned)(2 * (lbase + pair) + side) * (unsigned)SLOT * 4u, theirs = (unsigned)(2 * (lbase + pair) + (side ^ 1)) * (unsigned)SLOT * 4u;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            u32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(accm[i][j][4 * q + e]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), mine, 0x10);   // sc1: agent scope, write-through
-          }
-      MFC2_WAIT_VM(0);
-      if constexpr (MFC2_HZ_ON(4)) asm volatile("s_nop 15" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        // Publication.  The payload went out as 16-byte sc1 (write-through, agent scope) stores that every wave has waited for
-        // (vmcnt(0) + barrier above), the partner reads it with sc1 loads behind the counter: the {sc1 stores, sc1 loads} hand-off of
-        // MI355X_MICROARCH.md "Workgroup dispatch ... visibility".  tree == 2 adds the memory model's own fences around the counter
-        // (release = buffer_wbl2 sc1 + vmcnt(0) before the bump, acquire = buffer_inv sc1 after the second arriver's bump; one lane,
-        // then the barrier below) -- the form that does not lean on cache-policy bits; MF_CONV_TREE selects (conv_f16x2.hip).
-        if (p.tree == 2) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          MFC2_WAIT_VM(0);   // (restated where the compiler cannot drop it: ROCm 7.2 elides the wait behind buffer_wbl2 after an explicit vmcnt(0))
-        }
-        const unsigned old = __hip_atomic_fetch_add(cnt + lbase + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old) __hip_atomic_store(cnt + lbase + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // second: nobody touches it again in this launch
-        if (p.tree == 2 && old) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *flag = old;
-      }
-      __syncthreads();
-      const unsigned second = *flag;
-      __syncthreads();   // (the flag word is rewritten at the next level)
-      if (!second) return;            // the partner finishes this tile
-      if constexpr (MFC2_HZ_ON(3)) {   // every load landed before the first add
-        u32x4 pv[TM * TN * 4];
-#pragma unroll
-        for (int u = 0; u < TM * TN * 4; ++u) pv[u] = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(u * 1024), theirs, 0x10);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" ::: "memory");
-#if MFC2_HZ & 256
-        if (p.dbg) {   // [1]: this workgroup's own values, [2]: what it loaded from its partner (layout of [0], the sum dumped behind the tree)
-          const long plane = (long)p.tiles_m * p.tiles_n * NW * (TM * TN * 16 * 64);
-          float* o = p.dbg + ((long)tile * NW + wave) * (TM * TN * 16 * 64) + lane;
-#pragma unroll
-          for (int u = 0; u < TM * TN * 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              __builtin_nontemporal_store(accm[u / (4 * TN)][(u / 4) % TN][4 * (u % 4) + e], o + plane + (u * 4 + e) * 64);
-              __builtin_nontemporal_store(__uint_as_float(pv[u][e]), o + 2 * plane + (u * 4 + e) * 64);
-            }
-        }
-#endif
-#pragma unroll
-        for (int u = 0; u < TM * TN * 4; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) accm[u / (4 * TN)][(u / 4) % TN][4 * (u % 4) + e] += __uint_as_float(pv[u][e]);
-      } else {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rh, lane_off + (unsigned)(((i * TN + j) * 4 + q) * 1024), theirs, 0x10);   // sc1: past this XCD's L2
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if constexpr (MFC2_HZ_ON(5)) accm[i][j][4 * q + e] = hz_add(accm[i][j][4 * q + e], __uint_as_float(v[e]));
-              else accm[i][j][4 * q + e] += __uint_as_float(v[e]);
-            }
-          }
-      }
-      lbase += p.splitk >> (lv + 1);
-    }
-#if MFC2_HZ & 256
-    if (p.dbg) {
-      float* o = p.dbg + ((long)tile * NW + wave) * (TM * TN * 16 * 64) + lane;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(accm[i][j][r], o + ((i * TN + j) * 16 + r) * 64);
-    }
-#endif
-  }
-  const bool last_slice = p.splitk == 1 || p.tree;   // this workgroup holds final values: bias, statistics, bounds
-  constexpr int PITCH = FN * 4 + 16;                  // wave-private staging rows [32 pixels][FN couts] fp32 (+16 B: conflict-free b128 writes)
-  char* stg = smem + wave * (32 * PITCH);
-  static_assert(NW * 32 * PITCH <= NST * STAGE, "epilogue staging must fit in the pipeline stages");
-  constexpr int LPR = FN / 8, RPP = 64 / LPR, NPASS = 32 / RPP;   // lanes per pixel row (8 couts each), rows per pass, passes per sub-tile
-  const int rr = lane / LPR, c8 = lane % LPR;
-  const int col0 = n0 + wn * FN + c8 * 8;
-  float* out = p.y + (last_slice ? 0L : (long)kz * p.slab);
-  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-  if (last_slice && p.bias) {
-    b0 = *reinterpret_cast<const f32x4*>(p.bias + col0);
-    b1 = *reinterpret_cast<const f32x4*>(p.bias + col0 + 4);
-  }
-  float s1 = 0.f, s2 = 0.f, vmax = 0.f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {   // one 32-pixel sub-tile at a time through the wave's staging region (LDS operations of a wave stay in order)
-    MFC2_PIXEL_EXPS(i)
-    const float f_out = p.tree ? 1.f : exp2i(last_src2 ? e2_ : e1_) * exp2i(p.wexp);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if constexpr (MFC2_HZ_ON(6)) v[e] = hz_mul(hz_add(accm[i][j][4 * q + e], hz_mul(accx[i][j][4 * q + e], kLoInv)), f_out);
-          else v[e] = (accm[i][j][4 * q + e] + accx[i][j][4 * q + e] * kLoInv) * f_out;
-        }
-        *reinterpret_cast<f32x4*>(stg + (lane & 31) * PITCH + (j * 32 + 8 * q + 4 * fh) * 4) = v;
-        if constexpr (MFC2_HZ_ON(7)) asm volatile("s_nop 0" ::: "memory");
-        if constexpr (MFC2_HZ_ON(1)) asm volatile("s_nop %1" : "+v"(v) : "n"(MFC2_HZ_PAD) : "memory");   // the data registers stay untouched for PAD + 1 states
-      }
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP + rr;
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32);
-      f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * PITCH + c8 * 32 + 16);
-      if constexpr (MFC2_HZ_ON(2)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 3" : "+v"(v0), "+v"(v1)::"memory");
-      v0 += b0;
-      v1 += b1;
-      const int m = m0 + wm * FM + i * 32 + row;
-      if (m < p.M) {
-        long orow = m;
-        if (p.subpix) {  // row m = (n, phase, y, x) -> output pixel (n, 2y + a, 2x + b)
-          const int n = m / p.HWout, rem = m - n * p.HWout;
-          const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
-          const int y = r2 / p.Win, x = r2 - y * p.Win;
-          orow = ((long)n * p.Hout + 2 * y + (ph >> 1)) * p.Wout + 2 * x + (ph & 1);
-        }
-        *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0) = v0;
-        *reinterpret_cast<f32x4*>(out + orow * p.Cout + col0 + 4) = v1;
-        if (p.out_bound) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s1 += v0[e] + v1[e];
-          s2 = fmaf(v0[e], v0[e], s2);
-          s2 = fmaf(v1[e], v1[e], s2);
-        }
-      }
-    }
-  }
-  // A tile lies inside one sample (HWout % BM == 0), or -- small images -- holds BM / HWout whole samples, each a whole number of wave rows
-  // (HWout % FM == 0): the host guarantees one of the two whenever it asks for bounds or statistics.
-  const int wm_per_sample = p.HWout >= BM ? WM : p.HWout / FM;            // wave rows (wm) per sample inside this tile
-  const int n_first = m0 / p.HWout;                                        // first sample of the tile
-  if (p.out_bound) {   // slot (tile inside the sample, n-tile, wave inside the sample) of the wave's sample
-    vmax = wave_max(vmax);
-    const int n = n_first + wm / wm_per_sample;
-    const int part = p.HWout >= BM ? (m0 - n_first * p.HWout) / BM : 0;
-    const int wps = wm_per_sample * WN;                                    // waves per sample
-    if (lane == 0 && n < p.N) p.out_bound[(long)n * p.bound_slots + (part * p.tiles_n + tile_n) * wps + (wm % wm_per_sample) * WN + wn] = vmax;
-  }
-  if (p.gn_partial) {  // host guarantees: this workgroup holds final values, BN % cpg == 0, cpg % 8 == 0
-    __builtin_amdgcn_s_barrier();   // every wave has finished with its staging region
-    float* red = reinterpret_cast<float*>(smem);   // [NW waves][64 lanes][2]
-    red[(wave * 64 + lane) * 2] = s1;
-    red[(wave * 64 + lane) * 2 + 1] = s2;
-    MFC2_WAIT_LGKM0();
-    __builtin_amdgcn_s_barrier();
-    const int ngl = BN / p.gn_cpg, spt = WM / wm_per_sample;               // groups in the tile's channel range, samples per tile
-    if (tid < ngl * spt) {
-      const int gl = tid % ngl, si = tid / ngl;
-      double s = 0, q = 0;
-      const int slots = p.gn_cpg >> 3;
-      for (int k = 0; k < slots; ++k) {
-        const int slot8 = gl * slots + k;
-        const int wn_ = slot8 / LPR, c8_ = slot8 - wn_ * LPR;
-        for (int wm_ = si * wm_per_sample; wm_ < (si + 1) * wm_per_sample; ++wm_)
-          for (int r = 0; r < RPP; ++r) {
-            const float* d = red + ((wm_ * WN + wn_) * 64 + r * LPR + c8_) * 2;
-            s += (double)d[0];
-            q += (double)d[1];
-          }
-      }
-      const int n = n_first + si;
-      const int part = p.HWout >= BM ? (m0 - n_first * p.HWout) / BM : 0;
-      if (n < p.N) {
-        double* o = p.gn_partial + (((long)n * p.gn_parts + part) * p.gn_groups + (n0 / p.gn_cpg + gl)) * 2;
-        o[0] = s;
-        o[1] = q;
-      }
-    }
-  }
+#define MFC2_EPILOGUE_LDS_BYTES (NST * STAGE)
+#include "conv_f16x2_epilogue.inc"
+#undef MFC2_EPILOGUE_LDS_BYTES
 }
 
 // fp32 [rows][per_row] -> fp16 pairs, 8 consecutive elements per thread; row r is scaled by 2^-scale_exp_of(bound[r]) (bound null: unscaled)

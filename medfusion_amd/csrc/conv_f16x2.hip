@@ -5,21 +5,51 @@
 #include "gn_partial.h"
 #include "conv_plan.h"
 #include "conv_f16x2.h"
+#include "conv_f16x2_halo.h"
 
 using namespace mf;
 
 namespace {
 
 // ------------------------------------------------------------------ MF_CONV_FP32_F16X2: planning and launch (kernel: conv_f16x2.h)
-struct Tile2 { int id, BM, BN, WM, WN, NST; };   // LDS per workgroup = NST * (BM + BN) * 128 bytes; <= 80 KB: two workgroups per CU
+// HG = 0: conv_f16x2_kernel, LDS per workgroup = NST * (BM + BN) * 128 bytes (<= 80 KB: two workgroups per CU).
+// HG > 0: conv_halo_kernel (conv_f16x2_halo.h; 3x3 stride 1 only): the tile is a block of whole image rows, HG 1-KB halo pieces per wave
+//         and chunk; LDS = 2 HG NW KB (two halo buffers) + 3 BN * 128 (weight ring).
+struct Tile2 { int id, BM, BN, WM, WN, NST, HG; };
 const Tile2 kTiles2[] = {
-    {31, 128, 256, 2, 4, 3}, {32, 256, 128, 4, 2, 3}, {33, 128, 128, 2, 4, 3}, {34, 128, 128, 4, 2, 3}, {35, 256, 64, 4, 2, 3}, {36, 128, 64, 4, 2, 3},
-    {37, 64, 256, 1, 8, 3},
+    {31, 128, 256, 2, 4, 3, 0}, {32, 256, 128, 4, 2, 3, 0}, {33, 128, 128, 2, 4, 3, 0}, {34, 128, 128, 4, 2, 3, 0}, {35, 256, 64, 4, 2, 3, 0},
+    {36, 128, 64, 4, 2, 3, 0}, {37, 64, 256, 1, 8, 3, 0},
     // 4-wave workgroups, two per CU (independent barrier cadences on the two waves of a SIMD)
-    {51, 128, 128, 2, 2, 2}, {52, 128, 128, 2, 2, 3}, {53, 64, 128, 2, 2, 3}, {54, 128, 64, 2, 2, 3},
+    {51, 128, 128, 2, 2, 2, 0}, {52, 128, 128, 2, 2, 3, 0}, {53, 64, 128, 2, 2, 3, 0}, {54, 128, 64, 2, 2, 3, 0},
+    // halo tiles: activations staged once per chunk
+    {61, 256, 128, 4, 2, 3, 6}, {62, 256, 128, 4, 2, 3, 7}, {63, 128, 128, 2, 4, 3, 4}, {64, 128, 128, 2, 4, 3, 5},
 };
-inline int wgs_per_cu(const Tile2& t) { return (size_t)t.NST * (t.BM + t.BN) * 128 <= 80 * 1024 ? 2 : 1; }
+inline size_t tile_lds(const Tile2& t) {
+  return t.HG ? (size_t)2 * t.HG * (t.WM * t.WN) * 1024 + (size_t)3 * t.BN * 128 : (size_t)t.NST * (t.BM + t.BN) * 128;
+}
+inline int wgs_per_cu(const Tile2& t) { return tile_lds(t) <= 80 * 1024 ? 2 : 1; }
+// can the halo kernel take this convolution on tile t: 3x3 stride 1 pad 1, the tile a block of whole rows of one image or of whole small
+// images, its halo inside the HG pieces
+inline bool halo_fits(const MfConvDesc* d, const Tile2& t) {
+  if (!t.HG) return true;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->upsample != 0) return false;
+  const int W = d->Win, HW = d->Hin * d->Win;
+  int R, segs;
+  if (HW >= t.BM) {
+    if (HW % t.BM || t.BM % W) return false;
+    R = t.BM / W; segs = 1;
+  } else {
+    if (t.BM % HW) return false;
+    R = d->Hin; segs = t.BM / HW;
+  }
+  return (long)segs * (R + 2) * (W + 2) <= 8L * t.WM * t.WN * t.HG;
+}
 
+// MF_CONV_HALO: 1 (default) lets the planner's cost model consider the halo tiles, 0 keeps them for explicit tile hints
+inline bool halo_auto() {
+  static const int env = [] { const char* e = getenv("MF_CONV_HALO"); return e ? atoi(e) : 1; }();
+  return env != 0;
+}
 struct PlanEntry { int N, H, W, Cin, Cout, k, stride, ups, tile, sk; };
 const PlanEntry kPlanTable[] = {
 #include "conv_plan_table.inc"
@@ -56,7 +86,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   //   main loop                     ceil(workgroups / resident slots) * iterations * t_it(tile)
   //   split-K                       3 per level of the in-launch tree (power-of-two splits), else reducer 4 + (sk + 1) * output bytes / 3.5 TB/s
   const long out_bytes = (long)pl->M * d->Cout * 4;
-  auto valid = [&](const Tile2& k) { return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0); };
+  auto valid = [&](const Tile2& k) { return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0) && halo_fits(d, k); };
   auto sk_ok = [&](int sk) { return sk >= 1 && sk <= pl->cgroups; };
   auto chain_ok = [&](int sk) { return (long)cdiv(pl->cgroups, sk) * pl->taps <= 96; };  // the matrix core adds with truncation: one chain <= 96 chunks
   const Tile2* c = nullptr;   // fixed by the hint or the table, else chosen by the model
@@ -65,6 +95,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     for (const auto& k : kTiles2) if (k.id == d->tile_hint) c = &k;
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv(f16x2): bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
+    if (!halo_fits(d, *c)) { pl->ok = false; return MF_OK; }
   } else {
     for (const auto& e : kPlanTable) {
       if (e.N == d->N && e.H == d->Hin && e.W == d->Win && e.Cin == Cin && e.Cout == d->Cout && e.k == d->KH && e.stride == d->stride &&
@@ -83,6 +114,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     for (const auto& k : kTiles2) {
       if (c != nullptr && k.id != c->id) continue;   // tile already fixed
       if (c == nullptr && k.id == 52) continue;       // (A/B form of 51, never chosen automatically)
+      if (c == nullptr && k.HG && !halo_auto()) continue;
       if (!valid(k)) continue;
       const long tiles = (long)cdiv(pl->M, k.BM) * (d->Cout / k.BN);
       const int percu = wgs_per_cu(k);
@@ -132,6 +164,20 @@ int launch_f16x2_t(const mfc2::ConvP2& p, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int NST>
 int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s, int terms) {
   return terms == 1 ? launch_f16x2_t<BM, BN, WM, WN, NST, 1>(p, s) : launch_f16x2_t<BM, BN, WM, WN, NST, 3>(p, s);
+}
+template <int BM, int BN, int WM, int WN, int HG, int TERMS>
+int launch_halo_t(const mfc2::ConvP2& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)2 * HG * (WM * WN) * 1024 + (size_t)3 * BN * 128;
+  static DeviceOnce once;
+  if (first_use_on_device(once))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_halo_kernel<BM, BN, WM, WN, HG, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int grid = p.tiles_m * p.tiles_n * p.splitk;
+  MF_LAUNCH((mfc2::conv_halo_kernel<BM, BN, WM, WN, HG, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+  return check_launch("conv_halo");
+}
+template <int BM, int BN, int WM, int WN, int HG>
+int launch_halo(const mfc2::ConvP2& p, hipStream_t s, int terms) {
+  return terms == 1 ? launch_halo_t<BM, BN, WM, WN, HG, 1>(p, s) : launch_halo_t<BM, BN, WM, WN, HG, 3>(p, s);
 }
 
 // split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
@@ -325,6 +371,10 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
       case 52: rc = launch_f16x2<128, 128, 2, 2, 3>(p, s, terms); break;
       case 53: rc = launch_f16x2<64, 128, 2, 2, 3>(p, s, terms); break;
       case 54: rc = launch_f16x2<128, 64, 2, 2, 3>(p, s, terms); break;
+      case 61: rc = launch_halo<256, 128, 4, 2, 6>(p, s, terms); break;
+      case 62: rc = launch_halo<256, 128, 4, 2, 7>(p, s, terms); break;
+      case 63: rc = launch_halo<128, 128, 2, 4, 4>(p, s, terms); break;
+      case 64: rc = launch_halo<128, 128, 2, 4, 5>(p, s, terms); break;
       default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
     }
   }

@@ -134,10 +134,10 @@ def main():
         t_auto = time_conv(x1, x2, wt, b, d0, args.reps)
         res = []
         if not args.quick:
-            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54) if args.precision in (5, 6) else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
+            tiles = [int(t) for t in args.tiles.split(",")] if args.tiles else ((31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54, 61, 62, 63, 64) if args.precision in (5, 6) else (1, 3, 4, 7, 8, 9, 10) if args.precision else (1, 3, 4, 7, 8, 9, 23, 24, 27, 28))
             for tile in tiles:
-                bn = {31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 51: 128, 52: 128, 53: 128, 54: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
-                bm = {31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 51: 128, 52: 128, 53: 64, 54: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
+                bn = {61: 128, 62: 128, 63: 128, 64: 128, 31: 256, 32: 128, 33: 128, 34: 128, 35: 64, 36: 64, 37: 256, 51: 128, 52: 128, 53: 128, 54: 64, 1: 128, 2: 64, 3: 128, 4: 64, 7: 128, 8: 128, 9: 256, 10: 128, 11: 128, 12: 128, 13: 64, 23: 128, 24: 64, 27: 128, 28: 128}[tile]
+                bm = {61: 256, 62: 256, 63: 128, 64: 128, 31: 128, 32: 256, 33: 128, 34: 128, 35: 256, 36: 128, 37: 64, 51: 128, 52: 128, 53: 64, 54: 128, 1: 128, 2: 128, 3: 64, 4: 64, 7: 128, 8: 128, 9: 128, 10: 256, 11: 128, 12: 64, 13: 128, 23: 64, 24: 64, 27: 128, 28: 128}[tile]
                 if ups == 2 and (h * w_) % bm:
                     continue
                 if tile in (23, 24, 27, 28) and (c1 % 64 or c2 % 64):
@@ -152,6 +152,8 @@ def main():
                     if args.precision in (5, 6) and -(-((c1 + c2) // 32) // sk) * (4 if ups == 2 else k * k) > 96:
                         continue   # one accumulation chain <= 96 chunks (profiles/r02_split_accuracy.txt)
                     d = K.make_conv_desc(n, h, w_, c1, c2, co, k, st, pad, ups, tile_hint=tile, splitk_hint=sk, precision=args.precision)
+                    if args.precision in (5, 6) and not K.conv_f16x2_ok(d):
+                        continue   # (a halo tile this geometry does not fit)
                     res.append((time_conv(x1, x2, wt, b, d, args.reps), tile, sk))
             res.sort()
             t_auto = min(t_auto, time_conv(x1, x2, wt, b, d0, args.reps))   # (the first timing of a shape runs on clocks that are still ramping: long VAE rows lose 20 %)

@@ -564,14 +564,40 @@ F16X2_CASES = [
     (1, 16, 16, 256, 0, 256, 3, 1, 0),   # published 32^2-level shape (smaller HW)
     (2, 8, 8, 512, 512, 512, 3, 1, 0),   # out-block two-source, long K -> split-K
     (1, 7, 9, 96, 0, 192, 3, 1, 0),      # ragged M, Cout = 192
+    # geometries of the halo tiles (61-64: whole image rows per tile, activations staged once per chunk)
+    (2, 32, 32, 64, 0, 128, 3, 1, 0),    # 8 (tile 61) / 4 (tile 63) rows of a 32 x 32 image per tile
+    (3, 16, 16, 64, 64, 128, 3, 1, 0),   # one whole 16 x 16 image per 256-row tile, two-source
+    (5, 8, 8, 96, 32, 256, 3, 1, 0),     # four 8 x 8 images per 256-row tile (the last tile holds one), two per 128-row tile
+    (1, 64, 64, 32, 0, 128, 3, 1, 0),    # 64-wide image: 4 / 2 rows per tile
 ]
 F16X2_TILES = {31: (128, 256), 32: (256, 128), 33: (128, 128), 34: (128, 128), 35: (256, 64), 36: (128, 64), 37: (64, 256),
-               51: (128, 128), 52: (128, 128), 53: (64, 128), 54: (128, 64)}   # 51-54: 4-wave workgroups, two per CU
+               51: (128, 128), 52: (128, 128), 53: (64, 128), 54: (128, 64),   # 51-54: 4-wave workgroups, two per CU
+               61: (256, 128), 62: (256, 128), 63: (128, 128), 64: (128, 128)}   # 61-64: halo tiles (3x3 stride 1 only; HG = 6, 7, 4, 5)
+HALO_HG = {61: (6, 8), 62: (7, 8), 63: (4, 8), 64: (5, 8)}   # tile -> (halo pieces per wave, waves)
+
+
+def _halo_fits(case, tile):
+    n, h, w, c1, c2, co, k, stride, ups = case
+    if tile not in HALO_HG:
+        return True
+    bm, _ = F16X2_TILES[tile]
+    if k != 3 or stride != 1 or ups:
+        return False
+    if h * w >= bm:
+        if (h * w) % bm or bm % w:
+            return False
+        r, segs = bm // w, 1
+    else:
+        if bm % (h * w):
+            return False
+        r, segs = h, bm // (h * w)
+    hg, nw = HALO_HG[tile]
+    return segs * (r + 2) * (w + 2) <= 8 * nw * hg
 
 
 def _f16x2_tiles(case):
     n, h, w, c1, c2, co, k, stride, ups = case
-    return [0] + [t for t, (bm, bn) in F16X2_TILES.items() if co % bn == 0 and (ups != 2 or (h * w) % bm == 0)]
+    return [0] + [t for t, (bm, bn) in F16X2_TILES.items() if co % bn == 0 and (ups != 2 or (h * w) % bm == 0) and _halo_fits(case, t)]
 
 
 @pytest.mark.parametrize("case,tile", [(c, t) for c in F16X2_CASES for t in _f16x2_tiles(c)])
