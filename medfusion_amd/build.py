@@ -95,18 +95,25 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
-def build_variant(name: str, conv_flags=(), packed_fp32: bool = False, verbose: bool = False) -> Path:
+def build_variant(name: str, conv_flags=(), packed_fp32: bool = False, verbose: bool = False, unit_flags=None) -> Path:
     """A diagnostic twin of the library (csrc/build/variants/libmedfusion_hip_<name>.so; MEDFUSION_LIB=<path> makes lib.load() take it):
     conv_f16x2.hip recompiled with `conv_flags` (e.g. -DMFC2_HZ=2) and, with packed_fp32, WITHOUT the -packed-fp32-ops switch-off;
-    every other object is the product build's.  scripts/pk_hunt.py uses it to attribute a wrong result to one spot of the epilogue."""
+    `unit_flags` = {"groupnorm.hip": ["-DX=1"], ...} recompiles other units with extra flags; every other object is the product
+    build's.  scripts/pk_hunt.py uses it to attribute a wrong result to one spot of the epilogue, the A/B timing scripts for experiments."""
     build(verbose=verbose)
     vdir = OBJ / "variants"
     vdir.mkdir(exist_ok=True)
-    obj = vdir / f"conv_f16x2_{name}.o"
-    extra = [] if packed_fp32 else EXTRA_CFLAGS["conv_f16x2.hip"]
-    _run([hipcc(), *CFLAGS, *extra, *conv_flags, "-c", str(CSRC / "conv_f16x2.hip"), "-o", str(obj)], verbose)
+    flags = {k: list(v) for k, v in (unit_flags or {}).items()}
+    if conv_flags or packed_fp32 or not flags:
+        flags["conv_f16x2.hip"] = list(conv_flags) + flags.get("conv_f16x2.hip", [])
+    objs = {}
+    for src, fl in flags.items():
+        obj = vdir / f"{Path(src).stem}_{name}.o"
+        extra = [] if (packed_fp32 and src == "conv_f16x2.hip") else EXTRA_CFLAGS.get(src, [])
+        _run([hipcc(), *CFLAGS, *extra, *fl, "-c", str(CSRC / src), "-o", str(obj)], verbose)
+        objs[src] = obj
     lib = vdir / f"libmedfusion_hip_{name}.so"
-    _link([obj if s == "conv_f16x2.hip" else OBJ / (Path(s).stem + ".o") for s in SOURCES], lib, verbose)
+    _link([objs.get(s, OBJ / (Path(s).stem + ".o")) for s in SOURCES], lib, verbose)
     return lib
 
 

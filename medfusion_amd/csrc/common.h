@@ -86,5 +86,27 @@ static inline bool first_use_on_device(DeviceOnce& o) {
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
 // accurate variant used where parity margins are tight (embedding MLPs): expf, IEEE divide
 __device__ __forceinline__ float swish_acc(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+#ifndef MF_SWISH_APPLY
+#define MF_SWISH_APPLY 0
+#endif
+// the GroupNorm apply pass's form (VALU-bound pass: 28 of its ~55 instructions per element are this function).  0: swish_acc.
+// 1: the IEEE division (12 instructions) replaced by v_rcp_f32 + one Newton step (4; error < 1 ulp).  2: additionally expf without its
+// overflow / underflow selects (the sigmoid saturates by itself: exp -> inf gives x * 0, exp -> 0 gives x).
+__device__ __forceinline__ float swish_apply(float x) {
+#if MF_SWISH_APPLY == 0
+  return swish_acc(x);
+#else
+#if MF_SWISH_APPLY == 1
+  const float d = 1.0f + expf(-x);
+#else
+  const float a = -1.44269504088896341f * x, n = rintf(a);
+  const float f = (a - n) + (__builtin_fmaf(x, -1.44269504088896341f, -a) + x * -1.92596299112661746e-8f);   // a's rounding error, log2(e)'s low part
+  const float d = 1.0f + ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+#endif
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  return x * r;
+#endif
+}
 
 }  // namespace mf

@@ -28,6 +28,9 @@
 #ifndef MFC2_HZ
 #define MFC2_HZ 0   // diagnostic hooks (below): 0 in the product build
 #endif
+#ifndef MFC2_OUT_STORE
+#define MFC2_OUT_STORE 0   // 0: plain output stores; 1: non-temporal (A/B builds: medfusion_amd.build.build_variant; r03: +2 % on the convolution alone, nothing on the step)
+#endif
 
 namespace mfc2 {
 using namespace mf;

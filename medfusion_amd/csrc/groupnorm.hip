@@ -156,37 +156,83 @@ __global__ __launch_bounds__(256) void gn_apply_split_kernel(const float* __rest
 }
 
 // The pass fed by the PARTIAL records of the producing convolution -- no finalize launch in front of it.  grid (blocks per sample, N): a
-// block stays inside one sample, issues its first loads, and while they are in flight its first G threads reduce the sample's records
-// (fp64, the finalize kernel's formula) into LDS; the loop keeps one iteration of loads ahead of the arithmetic.
-template <bool SPLIT>
+// block stays inside one sample and handles U float4 per thread and round (thread t: float4 jw + 256 u + t); it issues the loads of its
+// first round, and while they are in flight reduces the sample's records (all 256 threads: 256 / G records per group side by side, fp64,
+// the finalize kernel's formula) into LDS.  The pass is VALU-bound, not HBM-bound, unless the per-element work is kept to the arithmetic
+// itself (r03: 560 -> ~200 instructions per float4): 32-bit indexing inside the sample, and -- when 256 % (C / 4) == 0, every published
+// width -- a thread's 4 channels are the same in every round, so mean / rstd / gamma / beta / embedding sit in registers.
+struct GnChan {
+  float mean[4], rstd[4], ga[4], be[4];
+  float4 em;
+};
+
+__device__ __forceinline__ GnChan gn_chan_consts(const float* sm, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ emb_row, int c, int cpg) {
+  GnChan k;
+  if (cpg % 4 == 0) {   // (c is a multiple of 4: one group)
+    const int g = c / cpg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k.mean[i] = sm[2 * g]; k.rstd[i] = sm[2 * g + 1]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int g = (c + i) / cpg; k.mean[i] = sm[2 * g]; k.rstd[i] = sm[2 * g + 1]; }
+  }
+  if (gamma) {
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    k.ga[0] = ga.x; k.ga[1] = ga.y; k.ga[2] = ga.z; k.ga[3] = ga.w;
+    k.be[0] = be.x; k.be[1] = be.y; k.be[2] = be.z; k.be[3] = be.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k.ga[i] = 1.f; k.be[i] = 0.f; }
+  }
+  k.em = emb_row ? *reinterpret_cast<const float4*>(emb_row + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  return k;
+}
+
+template <bool SPLIT, int U>
 __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restrict__ x, const double* __restrict__ partial, int parts, double count, float eps,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ residual, const float* __restrict__ emb, long emb_stride,
                                                             float* __restrict__ out, int HW, int C, int G, int act, const GnSplit sp) {
   __shared__ float sm[2 * 256 + 4];
+  __shared__ double sd[2 * 256];
   const int n = blockIdx.y, tid = threadIdx.x;
   const int C4 = C >> 2, cpg = C / G;
-  const long per4 = (long)HW * C4, base = (long)n * per4, step = (long)gridDim.x * 256;
-  long j = (long)blockIdx.x * 256 + tid;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), r = v;
+  const unsigned per4 = (unsigned)HW * (unsigned)C4;   // (host: < 2^31)
+  const long base = (long)n * per4;
+  constexpr unsigned SPAN = 256u * U;
+  const unsigned step = gridDim.x * SPAN;
   const bool res_p = SPLIT && sp.res_pairs != nullptr;                                    // the residual lives as fp16 pairs only
-  const float rsc = res_p ? exp2i(scale_exp_of(sp.res_bound[n])) : 1.f;
-  if (j < per4) {
-    v = *reinterpret_cast<const float4*>(x + (base + j) * 4);
-    if (res_p) r = load_pairs4(sp.res_pairs, (base + j) * 4, rsc);
-    else if (residual) r = *reinterpret_cast<const float4*>(residual + (base + j) * 4);
+  const bool res_f = !res_p && residual != nullptr;
+  const bool fixed_c = (256 % C4) == 0;
+  const float* emb_row = emb ? emb + (long)n * emb_stride : nullptr;
+
+  float4 v[U], r[U];
+  uint2 rh[U], rl[U];
+  unsigned jw = blockIdx.x * SPAN;
+#define GN_LOAD_ROUND()                                                                                                  \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                                        \
+    const unsigned j = jw + 256u * u + tid;                                                                              \
+    if (j < per4) {                                                                                                      \
+      v[u] = *reinterpret_cast<const float4*>(x + (base + j) * 4);                                                       \
+      if (res_p) {                                                                                                       \
+        const long e = (base + j) * 4;                                                                                   \
+        const uint2* g_ = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(sp.res_pairs) + (e >> 3) * 32 + ((e >> 2) & 1) * 8); \
+        rh[u] = g_[0]; rl[u] = g_[2];   /* [hi x 8] then [lo' x 8]: 16 bytes apart (load_pairs4) */                         \
+      } else if (res_f) r[u] = *reinterpret_cast<const float4*>(residual + (base + j) * 4);                              \
+    }                                                                                                                    \
   }
-  if (tid < G) {
+  if (jw < per4) GN_LOAD_ROUND()
+
+  {   // the sample's statistics: thread (kk, g) adds records kk, kk + PPT, ...; the first G threads add the PPT sums of their group
+    const int PPT = 256 / G, g = tid % G, kk = tid / G;
     double s = 0, q = 0;
-    for (int k = 0; k < parts; ++k) {
-      const double* p = partial + (((long)n * parts + k) * G + tid) * 2;
-      s += p[0]; q += p[1];
-    }
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0) var = 0;
-    sm[2 * tid] = (float)mean;
-    sm[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (kk < PPT)
+      for (int k = kk; k < parts; k += PPT) {
+        const double* p = partial + (((long)n * parts + k) * G + g) * 2;
+        s += p[0]; q += p[1];
+      }
+    sd[tid] = s; sd[256 + tid] = q;
   }
   if (SPLIT && sp.res_slots) {   // the residual's measured bound, straight from the slots its convolution wrote (no finalize launch)
     float m = 0.f;
@@ -195,40 +241,56 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
     if ((tid & 63) == 0) sm[2 * 256 + (tid >> 6)] = m;
   }
   __syncthreads();
-  float sc = 1.f;
+  if (tid < G) {
+    const int PPT = 256 / G;
+    double s = sd[tid], q = sd[256 + tid];
+    for (int kk = 1; kk < PPT; ++kk) { s += sd[kk * G + tid]; q += sd[256 + kk * G + tid]; }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0) var = 0;
+    sm[2 * tid] = (float)mean;
+    sm[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  float sc = 1.f, rsc = 1.f;
   if (SPLIT) {
     const float rb = sp.res_slots ? fmaxf(fmaxf(sm[512], sm[513]), fmaxf(sm[514], sm[515])) : (sp.res_bound ? sp.res_bound[n] : 0.f);
     const float b = sp.bconst + rb + (sp.emb_bound ? sp.emb_bound[n] : 0.f);
     sc = exp2i(-scale_exp_of(b));
+    if (res_p) rsc = exp2i(scale_exp_of(sp.res_bound[n]));
     if (blockIdx.x == 0 && tid == 0) sp.out_bound[n] = b;
   }
-  while (j < per4) {
-    const long jn = j + step;
-    float4 vn = v, rn = r;
-    if (jn < per4) {
-      vn = *reinterpret_cast<const float4*>(x + (base + jn) * 4);
-      if (res_p) rn = load_pairs4(sp.res_pairs, (base + jn) * 4, rsc);
-      else if (residual) rn = *reinterpret_cast<const float4*>(residual + (base + jn) * 4);
-    }
-    const int c = (int)(j % C4) * 4;
-    float e[4] = {v.x, v.y, v.z, v.w};
+  GnChan kc = gn_chan_consts(sm, gamma, beta, emb_row, fixed_c ? (tid % C4) * 4 : 0, cpg);
+
+  while (jw < per4) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int g = (c + k) / cpg;
-      float t = (e[k] - sm[2 * g]) * sm[2 * g + 1];
-      if (gamma) t = t * gamma[c + k] + beta[c + k];
-      if (act == 1) t = swish_acc(t);
-      e[k] = t;
+    for (int u = 0; u < U; ++u) {
+      const unsigned j = jw + 256u * u + tid;
+      if (j < per4) {
+        if (!fixed_c) kc = gn_chan_consts(sm, gamma, beta, emb_row, (int)(j % (unsigned)C4) * 4, cpg);
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = (e[k] - kc.mean[k]) * kc.rstd[k];
+          if (gamma) t = t * kc.ga[k] + kc.be[k];
+          if (act == 1) t = swish_apply(t);
+          e[k] = t;
+        }
+        if (res_p) {
+          const sf_f16x2 h0 = __builtin_bit_cast(sf_f16x2, rh[u].x), h1 = __builtin_bit_cast(sf_f16x2, rh[u].y),
+                         l0 = __builtin_bit_cast(sf_f16x2, rl[u].x), l1 = __builtin_bit_cast(sf_f16x2, rl[u].y);
+          e[0] += ((float)h0[0] + (float)l0[0] * kLoInv) * rsc; e[1] += ((float)h0[1] + (float)l0[1] * kLoInv) * rsc;
+          e[2] += ((float)h1[0] + (float)l1[0] * kLoInv) * rsc; e[3] += ((float)h1[1] + (float)l1[1] * kLoInv) * rsc;
+        } else if (res_f) { e[0] += r[u].x; e[1] += r[u].y; e[2] += r[u].z; e[3] += r[u].w; }
+        if (emb) { e[0] += kc.em.x; e[1] += kc.em.y; e[2] += kc.em.z; e[3] += kc.em.w; }
+        if (!SPLIT || out) *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);   // (null: pairs only)
+        if (SPLIT) store_split4(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);
+      }
     }
-    if (residual || res_p) { e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w; }
-    if (emb) {
-      const float4 m = *reinterpret_cast<const float4*>(emb + (long)n * emb_stride + c);
-      e[0] += m.x; e[1] += m.y; e[2] += m.z; e[3] += m.w;
-    }
-    if (!SPLIT || out) *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);   // (null: pairs only)
-    if (SPLIT) store_split4(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);
-    v = vn; r = rn; j = jn;
+    jw += step;
+    if (jw < per4) GN_LOAD_ROUND()
   }
+#undef GN_LOAD_ROUND
 }
 
 // max of |x| over this block's share of sample n -> partial[n][blockIdx.x * 4 + wave].  grid (blocks, N)
@@ -346,17 +408,24 @@ int mf_gn_apply_from_partials_pairs_f32(const float* x, const double* gn_partial
   const long per4 = (long)HW * (C / 4);
   const double nelem = (double)N * HW * C;
   ProfScope ps(MF_FAM_GN_APPLY, s, 8.0 * nelem, 4.0 * nelem * (1 + (out ? 1 : 0) + (residual || residual_pairs ? 1 : 0) + (out_split ? 1 : 0)));
-  long bps = (per4 + 255) / 256;
+  MF_REQUIRE(per4 < (1L << 31), MF_EUNSUPPORTED, "gn_apply_from_partials: %ld float4 per sample", per4);
+  // float4 per thread and round: as many as leave ~4 workgroups per CU over the whole launch (small tensors: more, shorter workgroups)
+  const long total_blocks = ((long)N * per4 + 255) / 256;
+  const int U = total_blocks >= 4 * 1024 ? 4 : total_blocks >= 2 * 1024 ? 2 : 1;
+  long bps = (per4 + 256 * U - 1) / (256 * U);
   const long cap = (256 * 8 + N - 1) / N;   // ~8 blocks per CU over the whole launch
   if (bps > cap) bps = cap;
   const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots, residual_pairs};
   const double count = (double)HW * (C / G);
-  if (out_split)
-    MF_LAUNCH(gn_apply_part_kernel<true>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
-                       (long)emb_stride, out, HW, C, G, act, sp);
-  else
-    MF_LAUNCH(gn_apply_part_kernel<false>, dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb,
-                       (long)emb_stride, out, HW, C, G, act, sp);
+#define GN_PART_LAUNCH(SPLIT_, U_)                                                                                                          \
+  MF_LAUNCH((gn_apply_part_kernel<SPLIT_, U_>), dim3((int)bps, N), dim3(256), 0, s, x, gn_partial, parts, count, eps, gamma, beta, residual, emb, \
+            (long)emb_stride, out, HW, C, G, act, sp)
+  if (out_split) {
+    if (U == 4) GN_PART_LAUNCH(true, 4); else if (U == 2) GN_PART_LAUNCH(true, 2); else GN_PART_LAUNCH(true, 1);
+  } else {
+    if (U == 4) GN_PART_LAUNCH(false, 4); else if (U == 2) GN_PART_LAUNCH(false, 2); else GN_PART_LAUNCH(false, 1);
+  }
+#undef GN_PART_LAUNCH
   return check_launch("gn_apply_from_partials");
 }
 
