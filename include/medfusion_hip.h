@@ -120,6 +120,10 @@ int mf_conv2d_f32(const float* x1, const float* x2, const float* w_packed, const
 int mf_conv2d_f16x2_ok(const MfConvDesc* d);
 int mf_conv2d_f16x2_bound_slots(const MfConvDesc* d);
 int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64_t per_row, void* stream);
+/* The same split when the bound of every row still lies as slot maxima -- slots [rows][nslots]: the y_bound array of mf_conv2d_f16x2 or
+ * the `partial` array of mf_maxabs_rows_f32 (bound = NULL there) -- reduced inside the pass, which also publishes bound_out[rows]: one
+ * launch instead of mf_bound_finalize_f32 + mf_split_f16x2 (7 launches fewer per denoise iteration of the published UNet). */
+int mf_split_f16x2_slots(const float* x, void* xs, const float* slots, int nslots, float* bound_out, int rows, int64_t per_row, void* stream);
 int mf_conv2d_f16x2_sync_words(const MfConvDesc* d);
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound,
                     const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync,

@@ -417,4 +417,29 @@ __global__ __launch_bounds__(256) void split_act_f16x2_kernel(const float* __res
   }
 }
 
+// The same split with the row's bound still lying as the [rows][nslots] slot maxima its producer left (the y_bound slots of a convolution,
+// the partial array of mf_maxabs_rows_f32): every workgroup of a row reduces the slots itself -- no mf_bound_finalize_f32 launch in front
+// of the split -- and workgroup 0 of the row publishes bound_out[row].  grid (blocks per row, rows)
+__global__ __launch_bounds__(256) void split_act_slots_kernel(const float* __restrict__ x, u32x4* __restrict__ out, long octets_per_row,
+                                                              const float* __restrict__ slots, int nslots, float* __restrict__ bound_out) {
+  __shared__ float sm[4];
+  const int row = blockIdx.y, tid = threadIdx.x;
+  float m = 0.f;
+  for (int i = tid; i < nslots; i += 256) m = fmaxf(m, slots[(long)row * nslots + i]);
+  m = mf::wave_max(m);
+  if ((tid & 63) == 0) sm[tid >> 6] = m;
+  __syncthreads();
+  const float b = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  if (blockIdx.x == 0 && tid == 0) bound_out[row] = b;
+  const float sc = exp2i(-scale_exp_of(b));
+  const long base = (long)row * octets_per_row;
+  for (long o = (long)blockIdx.x * 256 + tid; o < octets_per_row; o += (long)gridDim.x * 256) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + (base + o) * 8) * sc, v1 = *reinterpret_cast<const f32x4*>(x + (base + o) * 8 + 4) * sc;
+    u32x4 hi, lo;
+    split8_f16(v0, v1, hi, lo);
+    out[(base + o) * 2] = hi;
+    out[(base + o) * 2 + 1] = lo;
+  }
+}
+
 }  // namespace mfc2

@@ -291,6 +291,19 @@ int mf_split_f16x2(const float* x, void* xs, const float* bound, int rows, int64
   return check_launch("split_f16x2");
 }
 
+int mf_split_f16x2_slots(const float* x, void* xs, const float* slots, int nslots, float* bound_out, int rows, int64_t per_row, void* stream) {
+  MF_REQUIRE(x && xs && slots && bound_out && nslots > 0 && rows > 0 && rows <= 65535 && per_row > 0 && per_row % 8 == 0, MF_EINVAL,
+             "split_f16x2_slots: bad args (per_row %% 8 == 0, rows <= 65535)");
+  const long opr = per_row / 8;
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 8.0 * rows * (double)per_row);
+  long bpr = (opr + 255) / 256;
+  const long cap = (8192 + rows - 1) / rows;
+  if (bpr > cap) bpr = cap;
+  MF_LAUNCH(mfc2::split_act_slots_kernel, dim3((int)bpr, rows), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<mfc2::u32x4*>(xs), opr, slots, nslots,
+            bound_out);
+  return check_launch("split_f16x2_slots");
+}
+
 static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of (split_f16.h)
   if (!(bound > 0.f)) return 0;
   uint32_t u;

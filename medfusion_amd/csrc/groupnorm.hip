@@ -438,13 +438,13 @@ int mf_maxabs_rows_slots(int64_t per_row) {
 }
 
 int mf_maxabs_rows_f32(const float* x, float* partial, float* bound, int N, int64_t per_row, void* stream) {
-  MF_REQUIRE(x && partial && bound && N > 0 && per_row > 0 && per_row % 4 == 0 && N <= 65535, MF_EINVAL, "maxabs_rows: bad args (per_row %% 4 == 0)");
+  MF_REQUIRE(x && partial && N > 0 && per_row > 0 && per_row % 4 == 0 && N <= 65535, MF_EINVAL, "maxabs_rows: bad args (per_row %% 4 == 0)");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * N * (double)per_row);
   const int slots = mf_maxabs_rows_slots(per_row);
   MF_LAUNCH(maxabs_kernel, dim3(slots / 4, N), dim3(256), 0, s, x, partial, (long)(per_row / 4));
   int rc = check_launch("maxabs_rows");
-  if (rc) return rc;
+  if (rc || !bound) return rc;   // (bound null: the slots only -- their consumer reduces them itself, e.g. mf_split_f16x2_slots)
   MF_LAUNCH(bound_finalize_kernel, dim3(N), dim3(64), 0, s, partial, bound, slots);
   return check_launch("bound_finalize");
 }

@@ -221,7 +221,22 @@ def split_f16x2(x: torch.Tensor, bound: Optional[torch.Tensor] = None) -> torch.
 def split_of(x: torch.Tensor) -> torch.Tensor:
     s = _fresh(x, "_mf_split")
     if s is None:
-        s = split_f16x2(x, bound_of(x))
+        if _fresh(x, "_mf_bound") is None and x.dim() >= 2 and x.shape[-1] % 8 == 0 and x.is_contiguous() and x.dtype == torch.float32:
+            # no bound yet: the slot maxima the producing convolution left -- or those of a measuring pass -- are reduced inside the split
+            # itself (mf_split_f16x2_slots: no bound-finalize launch), which publishes the bound as well
+            _need_f32(x)
+            lib = L.load()
+            n, per = x.shape[0], x.numel() // x.shape[0]
+            sl = _fresh(x, "_mf_slots")
+            if sl is None:
+                sl = torch.empty((n, lib.mf_maxabs_rows_slots(per)), dtype=torch.float32, device=x.device)
+                L.check(lib.mf_maxabs_rows_f32(x.data_ptr(), sl.data_ptr(), None, n, per, stream()), "mf_maxabs_rows_f32")
+            s = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+            b = torch.empty((n,), dtype=torch.float32, device=x.device)
+            L.check(lib.mf_split_f16x2_slots(x.data_ptr(), s.data_ptr(), sl.data_ptr(), sl.shape[1], b.data_ptr(), n, per, stream()), "mf_split_f16x2_slots")
+            x._mf_bound = b
+        else:
+            s = split_f16x2(x, bound_of(x))
         x._mf_split = s
         _stamp(x)
     return s

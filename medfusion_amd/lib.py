@@ -50,6 +50,7 @@ _SIGS = {
     "mf_conv2d_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f16x2_ok": (_I, [C.POINTER(MfConvDesc)]),
     "mf_split_f16x2": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
+    "mf_split_f16x2_slots": (_I, [c_fp, c_fp, c_fp, _I, c_fp, _I, _I64, c_fp]),
     "mf_conv2d_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_sync_words": (_I, [C.POINTER(MfConvDesc)]),
     "mf_maxabs_rows_slots": (_I, [_I64]),

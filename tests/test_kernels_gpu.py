@@ -657,7 +657,7 @@ def test_conv_f16x2(dev, case, tile):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 32, 64, 3, 1, 0), (1, 16, 16, 256, 0, 256, 3, 1, 0), (2, 8, 8, 512, 512, 512, 3, 1, 0), (2, 8, 8, 64, 0, 128, 1, 1, 0),
-                                  (2, 5, 6, 32, 0, 64, 3, 1, 2), (3, 10, 12, 32, 0, 64, 3, 2, 0)])
+                                  (2, 8, 8, 32, 0, 256, 3, 1, 2), (3, 10, 12, 32, 0, 64, 3, 2, 0)])
 def test_conv_f16_single_term(dev, case):
     """MF_CONV_F16 (opt-in REDUCED precision): the fp16-pair operands and the LDS-DMA kernel with ONE product term, i.e. the
     operands rounded to fp16 -- on every tile and split-K the fp16-pair mode takes: error vs fp64 within the mode's own tolerance (2^-11 per
@@ -689,6 +689,25 @@ def test_conv_f16_single_term(dev, case):
             if sk == 1:   # one accumulation chain per element: the same bits on every tile (tile 0 / sk 0 is the planner's own choice: it may split K)
                 first = y if first is None else first
                 assert torch.equal(y, first), (case, tile)
+
+
+def test_split_from_slots_equals_finalize_then_split(dev):
+    """mf_split_f16x2_slots (the fp16-pair mirror of a tensor whose bound still lies as slot maxima -- the slots a measuring convolution
+    left, or those of mf_maxabs_rows_f32 with bound = NULL -- reduced inside the split) == mf_bound_finalize_f32 / mf_maxabs_rows_f32
+    followed by mf_split_f16x2, bit for bit, and it publishes the same bound"""
+    from medfusion_amd import kernels as K
+    n, h, w, ci, co = 3, 16, 16, 64, 128
+    x = K.nchw_to_nhwc(_rand("ss_x", (n, ci, h, w)).to(dev) * torch.tensor([1.0, 300.0, 1e-3], device=dev).view(n, 1, 1, 1))
+    w1, b1 = _rand("ss_w", (co, ci, 1, 1), 0.2).to(dev), _rand("ss_b", (co,), 0.1).to(dev)
+    d1 = K.make_conv_desc(n, h, w, ci, 0, co, 1, 1, 0, 0, precision=5)
+    y = K.conv2d_f16x2(x, K.split_weight_f16x2(K.pack_conv_weight(w1)), b1, d1, measure_out=True)
+    assert getattr(y, "_mf_slots", None) is not None and getattr(y, "_mf_bound", None) is None
+    want_b = y.abs().amax(dim=(1, 2, 3))
+    s = K.split_of(y)                                    # slots reduced inside the split
+    assert torch.equal(y._mf_bound, want_b) and torch.equal(s, K.split_f16x2(y, want_b))
+    z = _rand("ss_z", (5, 7, 9, 40)).to(dev) * torch.tensor([1.0, 0.0, 2e4, 3e-5, 7.0], device=dev).view(5, 1, 1, 1)   # (a zero row too)
+    s = K.split_of(z)                                    # no slots yet: one measuring launch (slots only) + the same split
+    assert torch.equal(z._mf_bound, z.abs().amax(dim=(1, 2, 3))) and torch.equal(s, K.split_f16x2(z, K.maxabs_rows(z)))
 
 
 def test_f16x2_operands_carry_nan_and_inf_and_never_go_stale(dev):
