@@ -241,7 +241,7 @@ def main():
     cond = (torch.arange(n_global, device=dev) % wl["classes"]) if wl["classes"] else None
     kw = dict(steps=wl["steps"], use_ddim=wl["use_ddim"])
     if args.graph:
-        kw["use_graph"] = True    # (default: denoise() decides -- graph replay only while the host would be the bottleneck)
+        kw["use_graph"] = True    # (default: denoise() decides -- the native command list wherever the iteration is replayable)
     if cond is not None:
         kw.update(guidance_scale=wl["guidance"], un_cond=None)
 

@@ -45,9 +45,10 @@ inline bool halo_fits(const MfConvDesc* d, const Tile2& t) {
   return (long)segs * (R + 2) * (W + 2) <= 8L * t.WM * t.WN * t.HG;
 }
 
-// MF_CONV_HALO: 1 (default) lets the planner's cost model consider the halo tiles, 0 keeps them for explicit tile hints
+// MF_CONV_HALO: 1 lets the planner's cost model consider the halo tiles; 0 (default: measured not faster than the 9-copy kernel on any
+// cfg2 shape but one, profiles/r03_conv_halo_sweep.txt) keeps them for explicit tile hints
 inline bool halo_auto() {
-  static const int env = [] { const char* e = getenv("MF_CONV_HALO"); return e ? atoi(e) : 1; }();
+  static const int env = [] { const char* e = getenv("MF_CONV_HALO"); return e ? atoi(e) : 0; }();
   return env != 0;
 }
 struct PlanEntry { int N, H, W, Cin, Cout, k, stride, ups, tile, sk; };
