@@ -88,6 +88,59 @@ __global__ void conv_direct_kernel(const ConvP p) {
 }
 
 
+// 1x1 output convolutions with a handful of output channels (UNet outc 256 -> 8, VAE outc 64 -> 3, the deep-supervision heads): NHWC
+// input, one source, C % 32 == 0, C / 32 a power of two <= 32, Cout <= 8.  C / 32 neighbouring lanes share a pixel, each reads 32 of its
+// channels ONCE (the generic kernel reads a pixel row once per output channel), multiplies them into Cout partial sums and the lanes of a
+// pixel add up with xor shuffles; lane q of a pixel stores outputs q, q + C/32, ...  grid: pixels / (256 / (C/32))
+template <int CO>
+__global__ __launch_bounds__(256) void conv_out1x1_kernel(const ConvP p) {
+  __shared__ float4 wsm[CO * 256];                        // the whole weight matrix [Cout][C] (C <= 1024)
+  const int lpp = p.C1 >> 5;                              // lanes per pixel
+  const int q = threadIdx.x & (lpp - 1);
+  const long m = ((long)blockIdx.x * 256 + threadIdx.x) / lpp;
+  const bool live = m < p.M;
+  float4 xv[8];
+  if (live) {
+    const float* xa = p.x1 + m * p.C1 + q * 32;           // (the activation loads are in flight while the weights go to LDS)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const float4*>(xa + 4 * i);
+  }
+  const int c4 = p.C1 >> 2;
+  for (int i = threadIdx.x; i < p.Cout * c4; i += 256) wsm[i] = reinterpret_cast<const float4*>(p.w)[i];
+  __syncthreads();
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      if (c < p.Cout) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 wv = wsm[c * c4 + q * 8 + i];
+          acc[c] = fmaf(xv[i].x, wv.x, acc[c]); acc[c] = fmaf(xv[i].y, wv.y, acc[c]);
+          acc[c] = fmaf(xv[i].z, wv.z, acc[c]); acc[c] = fmaf(xv[i].w, wv.w, acc[c]);
+        }
+      }
+    }
+  }
+  for (int off = 1; off < lpp; off <<= 1) {
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] += __shfl_xor(acc[c], off, 64);
+  }
+  if (!live) return;
+  const int n = (int)(m / p.HWout);
+  const long rem = m - (long)n * p.HWout;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    if (c < p.Cout && (c & (lpp - 1)) == q) {
+      const float v = acc[c] + (p.bias ? p.bias[c] : 0.f);
+      if (p.out_nchw) p.y[((long)n * p.Cout + c) * p.HWout + rem] = v;
+      else p.y[m * p.Cout + c] = v;
+    }
+  }
+}
+
 // Small-Cin convolution (UNet in_conv 8->256, VAE inc_dec 8->512, VAE inc 3->64): K = KH*KW*Cin <= 160.
 // A persistent block keeps a transposed weight tile W^T[k][co] (co <= 256) in LDS, then walks pixel groups:
 // the im2col patch of 16 pixels goes to LDS (broadcast reads), lane = output channel => coalesced NHWC stores.
@@ -100,9 +153,12 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int g
   const int tid = threadIdx.x;
   const int co0 = blockIdx.y * kSmallCo;
   const int nco = min(kSmallCo, p.Cout - co0);
-  for (int i = tid; i < nco * p.K; i += 256) {      // coalesced read of [co][k], transposed write
-    const int co = i / p.K, k = i - co * p.K;
-    wT[k * kSmallCo + co] = p.w[(long)(co0 + co) * p.K + k];
+  // thread = output channel: reads its weight row (stride K between lanes: the rows of a wave stay in L1 for the whole loop) and writes
+  // W^T with consecutive lanes on consecutive banks.  (The coalesced-read form -- lane = k -- stored with a stride of 256 floats: every
+  // lane of a wave on the same bank, 72 64-way conflicts per thread, ~8 us of the 35 us launch.)
+  if (tid < nco) {
+    const float* wr = p.w + (long)(co0 + tid) * p.K;
+    for (int k = 0; k < p.K; ++k) wT[k * kSmallCo + tid] = wr[k];
   }
   // thread = (pixel group pg of 4, channel quad cq of 64): 4 output channels x 16 pixels in registers
   const int pg = tid >> 6, cq = tid & 63;
@@ -469,6 +525,18 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     if (gx > 1024) gx = 1024;
     MF_LAUNCH(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
     return check_launch("conv_smallcin");
+  }
+  if (!pl.igemm && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->upsample == 0 && !p.in_nchw && d->C2 == 0 && d->Cout <= 8 &&
+      d->C1 % 32 == 0 && d->C1 / 32 <= 32 && ((d->C1 / 32) & (d->C1 / 32 - 1)) == 0) {
+    ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
+    const int lpp = d->C1 / 32;
+    const long blocks = ((long)pl.M * lpp + 255) / 256;
+    MF_REQUIRE(blocks < (1L << 31), MF_EUNSUPPORTED, "conv(out 1x1): %ld workgroups", blocks);
+    if (d->Cout <= 4)
+      MF_LAUNCH(conv_out1x1_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+      MF_LAUNCH(conv_out1x1_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return check_launch("conv_out1x1");
   }
   if (!pl.igemm) {
     ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);

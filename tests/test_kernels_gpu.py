@@ -162,6 +162,10 @@ def test_conv_split_bf16x3_wide_dynamic_range(dev):
     (1, 8, 8, 8, 512, 1, 1, "nchw", "nhwc"),    # its 1x1 conv_res
     (2, 9, 7, 3, 64, 3, 1, "nchw", "nhwc"),     # VAE inc 3->64
     (2, 6, 6, 16, 128, 3, 2, "nhwc", "nhwc"),
+    (3, 9, 7, 256, 8, 1, 1, "nhwc", "nchw"),    # conv_out1x1_kernel (UNet outc 256 -> 8): ragged pixel count, 8 lanes per pixel
+    (2, 8, 8, 128, 5, 1, 1, "nhwc", "nhwc"),    # 4 lanes per pixel, Cout not a multiple of them, NHWC out
+    (1, 5, 5, 1024, 2, 1, 1, "nhwc", "nchw"),   # 32 lanes per pixel
+    (2, 8, 8, 96, 4, 1, 1, "nhwc", "nchw"),     # C / 32 not a power of two: the generic kernel
 ])
 def test_conv_direct(dev, case):
     from medfusion_amd import kernels as K
