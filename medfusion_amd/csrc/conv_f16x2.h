@@ -68,7 +68,7 @@ struct ConvP2 {
   int tree;
   float* handoff;       // [tiles][2 (splitk - 1) slots][BM x BN floats]
   unsigned* sync;       // [tiles][splitk - 1] counters, zero between launches (the second arriver of a pair resets its counter)
-#if MFC2_HZ & 256
+#if MFC2_HZ & (256 | 512)
   float* dbg;           // diagnostic builds: [tiles][waves][TM][TN][16][64] the accumulators of the surviving workgroup right behind the tree
 #endif
 };
@@ -95,6 +95,14 @@ __device__ __forceinline__ float hz_add(float a, float b) { float r; asm volatil
 __device__ __forceinline__ float hz_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 #define MFC2_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+// MFC2_HZ bit 9 (diagnostic build, scripts/conv_timeline.py): workgroup `blockIdx.x` leaves the 100 MHz real-time counter at four points of its
+// life in p.dbg (as uint64 [grid][8]): 0 entry, 1 first chunk landed (end of the ramp), 2 end of the K loop, 3 end of the epilogue; inside the
+// epilogue: 4 every wave has left the loop (barrier), 5 split-K tree done, 6 outputs stored (issued), 7 unused
+#if MFC2_HZ & 512
+#define MFC2_STAMP(I) { if (p.dbg && threadIdx.x == 0) reinterpret_cast<unsigned long*>(p.dbg)[(long)blockIdx.x * 8 + (I)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define MFC2_STAMP(I)
+#endif
 #define MFC2_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // TERMS = 3: the fp32-class arithmetic above.  TERMS = 1 (MF_CONV_F16, opt-in REDUCED precision): only main += wh * xh -- the operands
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   static_assert((NR + NF - 1) / NF <= 3, "at most three reads per slot");
 
   extern __shared__ __attribute__((aligned(1024))) char smem[];
+  MFC2_STAMP(0)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,15 +267,44 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 
   f16x8 fx[2][TM][2], fw[2][TN][2];   // [step][sub-tile][piece]
 
-  // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source.  The exponents are
-  // re-derived from the bound arrays where they are needed (the source switch, the epilogue): nothing is kept live through the loop.
+  // per-pixel (= per-lane) operand scales: the accumulators hold sum(w 2^-wexp * x 2^-e), e = e1 or e2 by source.  The exponents are read
+  // from the bound arrays HERE, ahead of the first DMA (their round trip hides behind it; loads return in order, so the counted vmcnt waits
+  // of the pipeline are unaffected), and stay in 2 TM registers: fetched at the top of the epilogue they were a dependent ~1.5 us round trip
+  // with nothing to hide behind (scripts/conv_timeline.py: drain 4.2 us of a 57 us launch).
   const bool first_src1 = cg_beg * 32 < p.C1, last_src2 = (cg_end - 1) * 32 >= p.C1;
   const int it_sw = __builtin_amdgcn_readfirstlane((first_src1 && last_src2) ? (p.C1 / 32 - cg_beg) * taps : -1);   // first iteration that reads the second source
+#ifndef MFC2_EXPS_EARLY
+#define MFC2_EXPS_EARLY 1   // 0: the round-2 form (bounds fetched where they are used), for A/B builds
+#endif
+#if MFC2_EXPS_EARLY
+#define MFC2_PIXEL_EXPS_DECL()                                                                                          \
+  float pb1[TM] = {}, pb2[TM] = {};   /* the raw bounds: converted where they are used, nothing waits for them up here */ \
+  f32x4 eb0 = {0.f, 0.f, 0.f, 0.f}, eb1 = {0.f, 0.f, 0.f, 0.f};   /* the 8 bias values this lane adds in the epilogue */
+// issued BEHIND the DMA of the prologue (ahead of it they delayed the first chunk by 0.5 us: loads return in order); the counted vmcnt
+// waits then see 2 TM younger loads, i.e. at worst wait for that many loads of the next chunk as well
+#define MFC2_PIXEL_EXPS_LOAD()                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                                      \
+    const int pm_ = min(m0 + wm * FM + i * 32 + (lane & 31), p.M - 1);                                                  \
+    const int pn_ = pm_ / p.HWout;                                                                                      \
+    pb1[i] = p.bound1 ? p.bound1[pn_] : 0.f;                                                                            \
+    pb2[i] = (p.bound2 && p.C2 > 0) ? p.bound2[pn_] : 0.f;                                                              \
+  }                                                                                                                     \
+  if ((p.splitk == 1 || p.tree) && p.bias) {                                                                            \
+    const int bc0_ = n0 + wn * FN + (lane % (FN / 8)) * 8;                                                              \
+    eb0 = *reinterpret_cast<const f32x4*>(p.bias + bc0_);                                                               \
+    eb1 = *reinterpret_cast<const f32x4*>(p.bias + bc0_ + 4);                                                           \
+  }
+#define MFC2_PIXEL_EXPS(I) const int e1_ = p.bound1 ? scale_exp_of(pb1[I]) : 0, e2_ = (p.bound2 && p.C2 > 0) ? scale_exp_of(pb2[I]) : 0;
+#else
+#define MFC2_PIXEL_EXPS_DECL()
+#define MFC2_PIXEL_EXPS_LOAD()
 #define MFC2_PIXEL_EXPS(I)                                                                                              \
     const int pm_ = min(m0 + wm * FM + (I) * 32 + (lane & 31), p.M - 1);                                                \
     const int pn_ = pm_ / p.HWout;                                                                                      \
     const int e1_ = p.bound1 ? scale_exp_of(p.bound1[pn_]) : 0;                                                         \
     const int e2_ = (p.bound2 && p.C2 > 0) ? scale_exp_of(p.bound2[pn_]) : 0;
+#endif
+  MFC2_PIXEL_EXPS_DECL()
 #define MFC2_SOURCE_SWITCH()                                                                                            \
   if (__builtin_expect(it == it_sw, 0)) {                                                                               \
     if constexpr (MFC2_HZ_ON(0)) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                                     \
@@ -307,12 +345,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
 #pragma unroll
     for (int k = 1; k < NST; ++k)
       if (nit > k) { MFC2_LOAD_ALL() MFC2_LOAD_ADVANCE() }
+    MFC2_PIXEL_EXPS_LOAD()
     {
       const int g = min(nit, NST) - 1;   // chunk groups that may stay in flight
       if (g >= 5) { MFC2_WAIT_VM(5 * NL <= 63 ? 5 * NL : 0); } else if (g == 4) { MFC2_WAIT_VM(4 * NL <= 63 ? 4 * NL : 0); }
       else if (g == 3) { MFC2_WAIT_VM(3 * NL); } else if (g == 2) { MFC2_WAIT_VM(2 * NL); } else if (g == 1) { MFC2_WAIT_VM(NL); } else { MFC2_WAIT_VM(0); }
     }
     __builtin_amdgcn_s_barrier();
+    MFC2_STAMP(1)
     MFC2_READ_UNIT(0, 0, 0) MFC2_READ_UNIT(0, 0, 1)
     if constexpr (NR > 2) MFC2_READ_UNIT(0, 0, NR > 2 ? 2 : 0)
     if constexpr (NR > 3) MFC2_READ_UNIT(0, 0, NR > 3 ? 3 : 0)
@@ -398,9 +438,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
     st = st == NST - 1 ? 0 : st + 1;
   }
 
+  MFC2_STAMP(2)
 #define MFC2_EPILOGUE_LDS_BYTES (NST * STAGE)
 #include "conv_f16x2_epilogue.inc"
 #undef MFC2_EPILOGUE_LDS_BYTES
+  MFC2_STAMP(3)
 }
 
 // fp32 [rows][per_row] -> fp16 pairs, 8 consecutive elements per thread; row r is scaled by 2^-scale_exp_of(bound[r]) (bound null: unscaled)

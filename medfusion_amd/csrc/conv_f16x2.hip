@@ -234,7 +234,7 @@ size_t f16x2_workspace_bytes(const MfConvDesc* d) {
 }
 }  // namespace mf
 
-#if MFC2_HZ & 256
+#if MFC2_HZ & (256 | 512)
 static float* g_conv_dbg = nullptr;
 extern "C" void mf_debug_set_conv_dump(float* p) { g_conv_dbg = p; }   // diagnostic builds only (scripts/pk_dump.py)
 #endif
@@ -350,7 +350,7 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1));
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
-#if MFC2_HZ & 256
+#if MFC2_HZ & (256 | 512)
   p.dbg = g_conv_dbg;
 #endif
   const bool tree = pl.splitk > 1 && tree_possible(d, pl) && (!gn_partial || epilogue_stats_ok(d, pl, G));

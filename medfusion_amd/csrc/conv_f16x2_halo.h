@@ -237,6 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_halo_kernel(const ConvP2
     ws = wsn_;                                                                                                            \
   }
 
+  MFC2_PIXEL_EXPS_DECL()   // (operand scale exponents of this lane's pixels: conv_f16x2.h)
   if (nchunks > 0) {
     // ---- prologue: halo of the first chunk, weights of its first two taps; wait, barrier, first fragments
     int cc = cg_beg;
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_halo_kernel(const ConvP2
     MFH_W_ALL(cc, 0, 0)
     MFH_W_ALL(cc, 1, 1)
     MFH_W_ALL(cc, 2, 2)
+    MFC2_PIXEL_EXPS_LOAD()
     MFC2_WAIT_VM(2 * GQ);             // the halo and the weights of tap 0 have landed (taps 1 and 2 may still fly)
     __builtin_amdgcn_s_barrier();
     int hb = 0, ws = 0;
