@@ -149,33 +149,44 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_f16x2_kernel(const ConvP
   const int lrow = lane >> 3;
   const unsigned slot16 = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);
   int a_pix[GP], a_inv[GP];
+  // (this arithmetic runs on one wave per SIMD with nothing to hide behind -- ~1 us of a launch's ramp, scripts/conv_timeline.py -- so: divisions
+  // by the two uniform divisors through one float reciprocal each + a +-1 correction, exact below 2^23; the 9-bit tap mask from 3 + 3 row /
+  // column tests instead of 9 x 2)
+  const bool small_m = p.M < (1 << 23);
+  const float r_hw = 1.0f / (float)p.HWout, r_w = 1.0f / (float)(p.subpix ? p.Win : p.Wout), r_src = 1.0f / (float)p.hw_src;
+  auto qdiv = [small_m](int a, int d, float rd) {
+    if (!small_m) return a / d;
+    int q = (int)((float)a * rd);
+    const int r = a - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return q;
+  };
 #pragma unroll
   for (int i = 0; i < GP; ++i) {
     const int m = m0 + 8 * (wave + NW * i) + lrow;
     int n_ = 0, iy0 = -(1 << 28), ix0 = 0;   // rows past M: every tap "outside"
     if (m < p.M) {
-      const int n = m / p.HWout;
+      const int n = qdiv(m, p.HWout, r_hw);
       const int rem = m - n * p.HWout;
       n_ = n * p.Hin;
       if (p.subpix) {  // m = (n, phase, y, x) over the SOURCE grid; output pixel (2y + a, 2x + b)
-        const int ph = rem / p.hw_src, r2 = rem - ph * p.hw_src;
-        const int y = r2 / p.Win, x = r2 - y * p.Win;
+        const int ph = qdiv(rem, p.hw_src, r_src), r2 = rem - ph * p.hw_src;
+        const int y = qdiv(r2, p.Win, r_w), x = r2 - y * p.Win;
         iy0 = y + (ph >> 1) - 1;
         ix0 = x + (ph & 1) - 1;
       } else {
-        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        const int oy = qdiv(rem, p.Wout, r_w), ox = rem - oy * p.Wout;
         iy0 = oy * p.stride - p.pad;
         ix0 = ox * p.stride - p.pad;
       }
     }
-    unsigned valid = 0;
+    unsigned vy = 0, vx = 0;   // bit t: tap row / column t exists and lies inside the image
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        const bool in = ty < p.KH && tx < p.KW && (unsigned)(iy0 + ty) < (unsigned)p.Heff && (unsigned)(ix0 + tx) < (unsigned)p.Weff;
-        valid |= (in ? 1u : 0u) << (ty * p.KW + tx);
-      }
+    for (int t = 0; t < 3; ++t) {
+      vy |= (t < p.KH && (unsigned)(iy0 + t) < (unsigned)p.Heff ? 1u : 0u) << t;
+      vx |= (t < p.KW && (unsigned)(ix0 + t) < (unsigned)p.Weff ? 1u : 0u) << t;
+    }
+    const unsigned valid = ((vy & 1u) ? vx : 0u) | ((vy & 2u) ? vx << p.KW : 0u) | ((vy & 4u) ? vx << (2 * p.KW) : 0u);   // bit ty * KW + tx
     a_inv[i] = (int)~valid;
     a_pix[i] = (n_ + iy0) * p.Win + ix0;
   }
