@@ -40,6 +40,8 @@ CASES = [
     (16, 8, 8, 1536, 0, 512, 3, 53, 8),
     (16, 8, 8, 1024, 1024, 1024, 3, 31, 8),
     (16, 8, 8, 1024, 1024, 1024, 3, 51, 8),
+    (16, 32, 32, 256, 256, 256, 3, 62, 2),      # the two halo-tile plans of the product path (conv_plan_table.inc, round 3): two-source 3x3
+    (16, 16, 16, 512, 512, 512, 3, 62, 4),
 ]
 
 
