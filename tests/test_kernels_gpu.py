@@ -695,6 +695,45 @@ def test_conv_f16_single_term(dev, case):
                 assert torch.equal(y, first), (case, tile)
 
 
+def _halo_table_entries():
+    import re
+    out = []
+    for ln in (ROOT / "medfusion_amd" / "csrc" / "conv_plan_table.inc").read_text().splitlines():
+        m = re.match(r"\s*\{([^}]*)\},", ln)
+        if m:
+            v = [int(x) for x in m.group(1).split(",")]
+            if v[8] in HALO_HG:
+                out.append(tuple(v))
+    return out
+
+
+@pytest.mark.parametrize("entry", _halo_table_entries())
+def test_halo_plans_of_the_table_equal_the_nine_copy_kernel(dev, entry):
+    """every shape the planner table sends to the halo-tile kernel (round 3: the large 3x3 stride-1 convolutions of the bigger workloads):
+    the planner's own launch equals, bit for bit, the 9-copy kernel's launch with the same split-K (one association of the K slices), with
+    the GroupNorm records and with a second source where the shape is a skip concat of two equal halves"""
+    from medfusion_amd import kernels as K
+    n, h, w, cin, co, k, stride, ups, tile, sk = entry
+    two = cin >= 512 and (cin // 2) % 32 == 0          # (the up-path shapes: x ++ skip)
+    c1, c2 = (cin // 2, cin // 2) if two else (cin, 0)
+    g = torch.Generator().manual_seed(cin + co + n)
+    x1 = torch.randn((n, h, w, c1), generator=g).to(dev)
+    x2 = torch.randn((n, h, w, c2), generator=g).to(dev) * 3.0 if c2 else None
+    wt = (torch.randn((co, k, k, cin), generator=g) * 0.02).to(dev)
+    b = torch.randn((co,), generator=g).to(dev)
+    wh = K.split_weight_f16x2(wt)
+    d_auto = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, 1, ups, precision=5)
+    assert K.conv_plan(d_auto) == (tile, sk), (entry, K.conv_plan(d_auto))
+    other = 52 if co % 128 == 0 else 53
+    d_ref = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, 1, ups, tile_hint=other, splitk_hint=sk, precision=5)
+    assert K.conv_f16x2_ok(d_ref)
+    G = 32
+    ya, pa = K.conv2d_f16x2(x1, wh, b, d_auto, x2=x2, gn_groups=G, gn_parts=K.conv_gn_parts(d_auto, G))
+    yr, pr = K.conv2d_f16x2(x1, wh, b, d_ref, x2=x2, gn_groups=G, gn_parts=K.conv_gn_parts(d_ref, G))
+    assert torch.equal(ya, yr), entry
+    assert relerr(pa.sum(1), pr.sum(1)) < 1e-5, entry      # (the records differ in number and in the fp32 grouping of their per-lane sums)
+
+
 def test_split_from_slots_equals_finalize_then_split(dev):
     """mf_split_f16x2_slots (the fp16-pair mirror of a tensor whose bound still lies as slot maxima -- the slots a measuring convolution
     left, or those of mf_maxabs_rows_f32 with bound = NULL -- reduced inside the split) == mf_bound_finalize_f32 / mf_maxabs_rows_f32
