@@ -117,3 +117,37 @@ def test_no_packed_fp32_instruction_takes_the_high_half_of_src1():
     assert B.lint_isa() == []
     asm = (B.OBJ / "lint" / "conv_f16x2.s").read_text()
     assert "v_pk_mul_f32" not in asm and "v_pk_add_f32" not in asm and "v_pk_fma_f32" not in asm
+
+
+def test_command_list_host_contract():
+    """mf_cmdlist_* without a GPU: recording is per thread and exclusive (begin twice -> error), end without begin -> error, an empty list
+    has 0 launches and replays as a no-op, replay while recording is refused, free releases; every refusal leaves mf_last_error() set"""
+    import ctypes
+    import threading
+    from medfusion_amd import lib as L
+    lib = L.load()
+    h = ctypes.c_void_p()
+    assert lib.mf_cmdlist_end(ctypes.byref(h)) != 0 and b"not recording" in lib.mf_last_error()
+    assert lib.mf_cmdlist_begin() == 0
+    assert lib.mf_cmdlist_begin() != 0 and b"already recording" in lib.mf_last_error()
+    other = {}
+
+    def in_other_thread():      # another thread is NOT recording: it can begin / end its own list
+        hh = ctypes.c_void_p()
+        other["begin"] = lib.mf_cmdlist_begin()
+        other["end"] = lib.mf_cmdlist_end(ctypes.byref(hh))
+        other["count"] = lib.mf_cmdlist_count(hh)
+        lib.mf_cmdlist_free(hh)
+    t = threading.Thread(target=in_other_thread)
+    t.start()
+    t.join()
+    assert other == {"begin": 0, "end": 0, "count": 0}
+    empty = ctypes.c_void_p()
+    assert lib.mf_cmdlist_end(ctypes.byref(empty)) == 0 and empty.value
+    assert lib.mf_cmdlist_begin() == 0
+    assert lib.mf_cmdlist_replay(empty, 1, None) != 0 and b"recording" in lib.mf_last_error()     # (this thread records again)
+    assert lib.mf_cmdlist_end(ctypes.byref(h)) == 0
+    assert lib.mf_cmdlist_count(h) == 0 and lib.mf_cmdlist_count(None) == 0
+    assert lib.mf_cmdlist_replay(empty, 3, None) == 0        # nothing recorded: nothing launched (no device needed)
+    assert lib.mf_cmdlist_replay(None, 1, None) != 0 and lib.mf_cmdlist_replay(empty, -1, None) != 0
+    assert lib.mf_cmdlist_free(h) == 0 and lib.mf_cmdlist_free(empty) == 0
