@@ -300,6 +300,11 @@ int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float*
  * NHWC fp32, C % 4 == 0. */
 int mf_avgpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream);
 int mf_upsample_nearest2x_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* The `use_res` skips of BasicDown / BasicUp (conv_blocks.py:54-55,68-69 and :114-115,125-126), added in place to the convolution's output:
+ * y [N][H/2][W/2][4C] += PixelUnshuffle(2)(x [N][H][W][C])   (channel c * 4 + dy * 2 + dx <- pixel (2h + dy, 2w + dx), torch's order), H, W even;
+ * y [N][2H][2W][C/4]  += PixelShuffle(2)(x [N][H][W][C]),    C % 4 == 0. */
+int mf_pixel_unshuffle2_add_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int mf_pixel_shuffle2_add_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 
 /* Image egress on the device: NCHW float -> NHWC uint8.
  * mode 0: scripts/helpers/sample_dataset.py:44-53  clip(-1,1) -> (x+1)/2*255 -> astype(uint8)   (bit-exact vs numpy)

@@ -355,15 +355,14 @@ class UnetBasicBlock(_EmbBlock):
 
 
 class BasicDown(nn.Module):
-    """conv_blocks.py:28-70.  Learnable: 3x3 stride-s conv (key `down_op.*`); learnable_interpolation=False: nn.AvgPool2d(k, stride,
-    get_padding(k, stride)), no parameters, the channel count stays.  `use_res` (PixelUnshuffle skip, :54-55) is never set by the reference's
-    models (DownBlock :397 and unet2.py:107-114 pass / default False) and is not built."""
+    """conv_blocks.py:28-70.  Learnable: 3x3 stride-s conv (key `down_op.*`), plus -- `use_res` -- nn.PixelUnshuffle(2)(x) added to its output
+    (:54-55,68-69; needs out_channels == 4 in_channels; no model of the reference sets it, built for completeness);
+    learnable_interpolation=False: nn.AvgPool2d(k, stride, get_padding(k, stride)), no parameters, the channel count stays."""
 
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=3, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
-        if use_res:
-            raise NotImplementedError("BasicDown(use_res=True): the PixelUnshuffle skip is unreachable from the reference's models and not built")
         self.learnable = bool(learnable_interpolation)
+        self.use_res = bool(use_res) and self.learnable        # (the reference creates `down_skip` inside the learnable branch only)
         if self.learnable:
             self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
         else:
@@ -371,29 +370,37 @@ class BasicDown(nn.Module):
 
     def forward(self, x, emb=None):
         if self.learnable:
-            return self.down_op(x, measure_out=f16x2_mode())
+            if not self.use_res:
+                return self.down_op(x, measure_out=f16x2_mode())
+            if isinstance(x, (tuple, list)):
+                raise RuntimeError("BasicDown(use_res=True) takes one tensor")
+            return K.pixel_unshuffle2_add(x, self.down_op(x))   # (the sum is measured by its first fp16-pair consumer)
         if isinstance(x, (tuple, list)):
             raise RuntimeError("BasicDown(learnable_interpolation=False) takes one tensor")
         return K.avgpool2d(x, self.k, self.stride, self.pad)
 
 
 class BasicUp(nn.Module):
-    """conv_blocks.py:72-131: nearest-exact x2 then 3x3 conv, fused into one gather (key `up_op.*`); learnable_interpolation=False: the plain
-    nearest-exact resize (:128-130), no parameters.  `use_res` (PixelShuffle skip, :114-115): see BasicDown."""
+    """conv_blocks.py:72-131: nearest-exact x2 then 3x3 conv, fused into one gather (key `up_op.*`), plus -- `use_res` -- nn.PixelShuffle(2)(x)
+    added to its output (:114-115,125-126; out_channels == in_channels / 4); learnable_interpolation=False: the plain nearest-exact resize
+    (:128-130), no parameters."""
 
     def __init__(self, spatial_dims, in_channels, out_channels, kernel_size=2, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
-        if use_res:
-            raise NotImplementedError("BasicUp(use_res=True): the PixelShuffle skip is unreachable from the reference's models and not built")
         if (kernel_size, stride) != (2, 2):
             raise NotImplementedError("BasicUp: only x2 upsampling (kernel_size=stride=2) is supported")
         self.learnable = bool(learnable_interpolation)
+        self.use_res = bool(use_res) and self.learnable
         if self.learnable:
             self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
 
     def forward(self, x, emb=None):
         if self.learnable:
-            return self.up_op(x, measure_out=f16x2_mode())
+            if not self.use_res:
+                return self.up_op(x, measure_out=f16x2_mode())
+            if isinstance(x, (tuple, list)):
+                raise RuntimeError("BasicUp(use_res=True) takes one tensor")
+            return K.pixel_shuffle2_add(x, self.up_op(x))
         if isinstance(x, (tuple, list)):
             raise RuntimeError("BasicUp(learnable_interpolation=False) takes one tensor")
         return K.upsample_nearest2x(x)

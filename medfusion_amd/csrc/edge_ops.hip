@@ -137,7 +137,63 @@ __global__ __launch_bounds__(256) void upsample_nearest2_nhwc_kernel(const float
   }
 }
 
+// y[n][h][w][c * 4 + dy * 2 + dx] += x[n][2 h + dy][2 w + dx][c]   -- nn.PixelUnshuffle(2) added to the stride-2 convolution's output
+// (conv_blocks.py:54-55,68-69: BasicDown(use_res=True), out_channels == 4 in_channels).  One thread per output float4 = one input
+// channel's 2 x 2 neighbourhood.
+__global__ __launch_bounds__(256) void pixel_unshuffle2_add_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int Ho, int Wo, int C) {
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int w = (int)(r % Wo);
+    r /= Wo;
+    const int h = (int)(r % Ho), n = (int)(r / Ho);
+    const float* s = x + (((long)n * 2 * Ho + 2 * h) * (2 * Wo) + 2 * w) * C + c;
+    float4 v = *reinterpret_cast<float4*>(y + i * 4);
+    v.x += s[0]; v.y += s[C]; v.z += s[(long)2 * Wo * C]; v.w += s[(long)2 * Wo * C + C];
+    *reinterpret_cast<float4*>(y + i * 4) = v;
+  }
+}
+
+// y[n][2 h + dy][2 w + dx][c] += x[n][h][w][c * 4 + dy * 2 + dx]   -- nn.PixelShuffle(2) added to the up-convolution's output
+// (conv_blocks.py:114-115,125-126: BasicUp(use_res=True), out_channels == in_channels / 4).  One thread per input float4.
+__global__ __launch_bounds__(256) void pixel_shuffle2_add_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int Co) {
+  const long total = (long)N * H * W * Co;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Co);
+    long r = i / Co;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H), n = (int)(r / H);
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    float* d = y + (((long)n * 2 * H + 2 * h) * (2 * W) + 2 * w) * Co + c;
+    d[0] += v.x; d[Co] += v.y; d[(long)2 * W * Co] += v.z; d[(long)2 * W * Co + Co] += v.w;
+  }
+}
+
 extern "C" {
+
+int mf_pixel_unshuffle2_add_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, MF_EINVAL, "pixel_unshuffle2_add: bad args (H, W even)");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * (H / 2) * (W / 2) * C;
+  ProfScope ps(MF_FAM_MISC, s, 4.0 * total, 4.0 * 12.0 * total);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MF_LAUNCH(pixel_unshuffle2_add_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, N, H / 2, W / 2, C);
+  return check_launch("pixel_unshuffle2_add");
+}
+
+int mf_pixel_shuffle2_add_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MF_EINVAL, "pixel_shuffle2_add: bad args (C %% 4 == 0)");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)N * H * W * (C / 4);
+  ProfScope ps(MF_FAM_MISC, s, 4.0 * total, 4.0 * 12.0 * total);
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  MF_LAUNCH(pixel_shuffle2_add_kernel, dim3((int)blocks), dim3(256), 0, s, x, y, N, H, W, C / 4);
+  return check_launch("pixel_shuffle2_add");
+}
 
 int mf_avgpool2d_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad, void* stream) {
   MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MF_EINVAL, "avgpool2d: bad args (C %% 4 == 0)");

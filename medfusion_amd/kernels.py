@@ -662,6 +662,30 @@ def upsample_nearest2x(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pixel_unshuffle2_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """y [N, H/2, W/2, 4C] += nn.PixelUnshuffle(2)(x [N, H, W, C]) on NHWC, in place (BasicDown(use_res=True))"""
+    _gpu(x, y)
+    _need_f32(x, y)
+    n, h, w, c = x.shape
+    if y.shape != (n, h // 2, w // 2, 4 * c) or h % 2 or w % 2:
+        raise RuntimeError(f"pixel_unshuffle2_add: x {tuple(x.shape)} does not unshuffle onto y {tuple(y.shape)}")
+    drop_split(y)
+    L.check(L.load().mf_pixel_unshuffle2_add_nhwc_f32(x.contiguous().data_ptr(), y.data_ptr(), n, h, w, c, stream()), "mf_pixel_unshuffle2_add_nhwc_f32")
+    return y
+
+
+def pixel_shuffle2_add(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """y [N, 2H, 2W, C/4] += nn.PixelShuffle(2)(x [N, H, W, C]) on NHWC, in place (BasicUp(use_res=True))"""
+    _gpu(x, y)
+    _need_f32(x, y)
+    n, h, w, c = x.shape
+    if c % 4 or y.shape != (n, 2 * h, 2 * w, c // 4):
+        raise RuntimeError(f"pixel_shuffle2_add: x {tuple(x.shape)} does not shuffle onto y {tuple(y.shape)}")
+    drop_split(y)
+    L.check(L.load().mf_pixel_shuffle2_add_nhwc_f32(x.contiguous().data_ptr(), y.data_ptr(), n, h, w, c, stream()), "mf_pixel_shuffle2_add_nhwc_f32")
+    return y
+
+
 def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     _gpu(moments_nchw, noise)
     n, c2, h, w = moments_nchw.shape

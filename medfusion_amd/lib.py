@@ -80,6 +80,8 @@ _SIGS = {
     "mf_image_egress_u8": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, _I, _I, c_fp]),
     "mf_avgpool2d_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, _I, _I, _I, c_fp]),
     "mf_upsample_nearest2x_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_pixel_unshuffle2_add_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_pixel_shuffle2_add_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_counter_add_i32": (_I, [c_fp, C.c_int32, c_fp]),
     "mf_philox_normal_f32": (_I, [c_fp, _U64, C.c_int32, C.c_int32, c_fp, C.c_int32, _I64, _I, _I64, c_fp]),
     "mf_attention_f32": (_I, [c_fp, c_fp, c_fp, c_fp, _I, _I, _I, _I, _I, _F, c_fp]),

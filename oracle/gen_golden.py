@@ -218,6 +218,24 @@ def case_nonlearnable():
 
 
 @torch.no_grad()
+def case_use_res():
+    """BasicDown / BasicUp with use_res=True (conv_blocks.py:54-55,68-69 and :114-115,125-126: PixelUnshuffle / PixelShuffle skips; no model of
+    the reference sets it): the reference's own outputs"""
+    out = {}
+    ref, ora = RC.BasicDown(2, 32, 128, 3, 2, use_res=True), R.BasicDown(32, 128, 3, 2, use_res=True)
+    synth_pair(ref, ora, "ur_down.")
+    xd = S.synth_input("ur_down_x", (2, 32, 10, 12))
+    check_equal("ur_down", ref(xd), ora(xd))
+    out.update(down_x=xd, down_y=ref(xd), **{f"down.{k}": v for k, v in ref.state_dict().items()})
+    ref, ora = RC.BasicUp(2, 128, 32, 2, 2, use_res=True), R.BasicUp(128, 32, 2, 2, use_res=True)
+    synth_pair(ref, ora, "ur_up.")
+    xu = S.synth_input("ur_up_x", (2, 128, 5, 6))
+    check_equal("ur_up", ref(xu), ora(xu))
+    out.update(up_x=xu, up_y=ref(xu), **{f"up.{k}": v for k, v in ref.state_dict().items()})
+    save("blocks_use_res", **out)
+
+
+@torch.no_grad()
 def case_unets():
     x = S.synth_input("unet_x", (2, 8, 8, 8))
     t = torch.tensor([37, 37])
@@ -376,7 +394,7 @@ def case_cfg1_published():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    cases = [case_scheduler, case_embedders, case_blocks, case_nonlearnable, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
+    cases = [case_scheduler, case_embedders, case_blocks, case_nonlearnable, case_use_res, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
     for fn in cases:
         if only and fn.__name__ not in only:
             continue

@@ -149,28 +149,35 @@ class SequentialEmb(nn.Sequential):
 
 
 class BasicDown(nn.Module):
-    """Learnable: 3x3 stride-s conv; else AvgPool.  conv_blocks.py:28-70."""
+    """Learnable: 3x3 stride-s conv (+ nn.PixelUnshuffle(2) skip with use_res, :54-55,68-69); else AvgPool.  conv_blocks.py:28-70."""
 
-    def __init__(self, in_ch, out_ch, kernel_size=3, stride=2, learnable_interpolation=True):
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
         if learnable_interpolation:
             self.down_op = nn.Conv2d(in_ch, out_ch, kernel_size, stride, monai_padding(kernel_size, stride), bias=True)
+            if use_res:
+                self.down_skip = nn.PixelUnshuffle(2)
         else:
             self.down_op = nn.AvgPool2d(kernel_size, stride, monai_padding(kernel_size, stride))
 
     def forward(self, x, emb=None):
-        return self.down_op(x)
+        y = self.down_op(x)
+        if hasattr(self, "down_skip"):
+            y = y + self.down_skip(x)
+        return y
 
 
 class BasicUp(nn.Module):
     """nearest-exact resize to (n-1)*s + k - 2*pad, then 3x3 s1 conv.  conv_blocks.py:72-131."""
 
-    def __init__(self, in_ch, out_ch, kernel_size=2, stride=2, learnable_interpolation=True):
+    def __init__(self, in_ch, out_ch, kernel_size=2, stride=2, learnable_interpolation=True, use_res=False):
         super().__init__()
         self.learnable_interpolation = learnable_interpolation
         self._k, self._s = kernel_size, stride
         if learnable_interpolation:
             self.up_op = nn.Conv2d(in_ch, out_ch, 3, 1, 1, bias=True)
+            if use_res:
+                self.up_skip = nn.PixelShuffle(2)   # conv_blocks.py:114-115
 
     def calc_shape(self, spatial):
         pad = monai_padding(self._k, self._s)
@@ -178,7 +185,12 @@ class BasicUp(nn.Module):
 
     def forward(self, x, emb=None):
         x_res = F.interpolate(x, size=self.calc_shape(x.shape[2:]), mode="nearest-exact")
-        return self.up_op(x_res) if self.learnable_interpolation else x_res
+        if not self.learnable_interpolation:
+            return x_res
+        y = self.up_op(x_res)
+        if hasattr(self, "up_skip"):   # conv_blocks.py:125-126
+            y = y + self.up_skip(x)
+        return y
 
 
 class DownBlock(nn.Module):

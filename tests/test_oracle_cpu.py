@@ -139,6 +139,18 @@ def test_nonlearnable_down_up_and_unet():
     assert relerr(y, T(g["y"])) <= TOL
 
 
+@torch.no_grad()
+def test_use_res_down_up():
+    """BasicDown / BasicUp with use_res=True (PixelUnshuffle / PixelShuffle skips, conv_blocks.py:54-55,68-69,114-115,125-126) against what the
+    REFERENCE computed (oracle/gen_golden.py::case_use_res)"""
+    g = gold("blocks_use_res")
+    d, u = R.BasicDown(32, 128, 3, 2, use_res=True), R.BasicUp(128, 32, 2, 2, use_res=True)
+    S.synth_state_dict(d, "ur_down.")
+    S.synth_state_dict(u, "ur_up.")
+    assert torch.equal(d(T(g["down_x"])), T(g["down_y"]))
+    assert torch.equal(u(T(g["up_x"])), T(g["up_y"]))
+
+
 REFTEST_KW = dict(in_ch=3, out_ch=3, spatial_dims=2, hid_chs=[32, 64, 128, 256], kernel_sizes=[1, 3, 3, 3], strides=[1, 2, 2, 2],
                   time_embedder=R.TimeEmbbeding, time_embedder_kwargs={"emb_dim": 64}, cond_embedder=R.LabelEmbedder,
                   cond_embedder_kwargs={"emb_dim": 64, "num_classes": 2}, deep_supervision=True, use_res_block=True, use_attention="linear")

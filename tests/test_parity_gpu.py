@@ -91,14 +91,29 @@ def test_nonlearnable_down_up_golden(dev):
     for tag in ("even", "odd"):
         assert torch.equal(nchw(d(nhwc(T(g[f"down_{tag}_x"]), dev))), T(g[f"down_{tag}_y"])), tag
     assert torch.equal(nchw(u(nhwc(T(g["up_x"]), dev))), T(g["up_y"]))
-    with pytest.raises(NotImplementedError):
-        B.BasicDown(2, 32, 128, 3, 2, use_res=True)
     g = gold("unet_tiny_nonlearnable")
     m = M.UNet(**to_product_kwargs(R.tiny_unet_kwargs(2, "none", learnable_interpolation=False)))
     S.synth_state_dict(m, "unet_nonlearnable.")
     m.to(dev)
     y, _ = m(T(g["x"]).to(dev), T(g["t"]).to(dev), T(g["cond"]).to(dev))
     assert relerr(y, T(g["y"])) < TOL
+
+
+def test_use_res_down_up_golden(dev):
+    """BasicDown / BasicUp with use_res=True: the stride-2 / up convolution plus the PixelUnshuffle / PixelShuffle skip of the input
+    (mf_pixel_unshuffle2_add_nhwc_f32, mf_pixel_shuffle2_add_nhwc_f32) against the reference's outputs; the sum carries no stale operand mirror"""
+    from medfusion_amd import blocks as B
+    from medfusion_amd import kernels as K
+    g = gold("blocks_use_res")
+    d, u = B.BasicDown(2, 32, 128, 3, 2, use_res=True), B.BasicUp(2, 128, 32, 2, 2, use_res=True)
+    S.synth_state_dict(d, "ur_down.")
+    S.synth_state_dict(u, "ur_up.")
+    yd = d.to(dev)(nhwc(T(g["down_x"]), dev))
+    assert relerr(nchw(yd), T(g["down_y"])) < TOL
+    yu = u.to(dev)(nhwc(T(g["up_x"]), dev))
+    assert relerr(nchw(yu), T(g["up_y"])) < TOL
+    for y in (yd, yu):     # whoever reads the sum as a convolution operand measures IT, not the convolution's output before the add
+        assert torch.equal(K.bound_of(y), y.abs().amax(dim=(1, 2, 3)))
 
 
 def test_attention_golden(dev):
