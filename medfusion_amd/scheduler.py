@@ -216,7 +216,11 @@ class GaussianNoiseScheduler(BasicNoiseScheduler):
         return K.rows_axpby(mean, None, noise, std.to(x_t.device)), x_0
 
     def sample(self, x_0):
-        raise NotImplementedError("scheduler.sample() draws training timesteps (scheduler_base.py:19-23): training is out of scope")
+        """scheduler_base.py:20-24 (the training-side entry of the forward process; kept for API completeness): one random t in [0, T) per
+        row (torch's generator of x_0's device, like the reference), x_T = x_final(x_0), returns (x_t, x_T, t)."""
+        t = torch.randint(0, self.T, (x_0.shape[0],), dtype=torch.long, device=x_0.device)
+        x_T = self.x_final(x_0)
+        return self.estimate_x_t(x_0, t, x_T), x_T, t
 
     @classmethod
     def x_final(cls, x):

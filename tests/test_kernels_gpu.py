@@ -500,6 +500,11 @@ def test_scheduler_tensor_api_per_row_t_bit_exact(dev):
         assert torch.equal(pa.cpu(), oa) and torch.equal(pb.cpu(), ob)
     assert torch.equal(psch.estimate_mean_t(D(xt), D(x0), D(t)).cpu(), osch.estimate_mean_t(xt, x0, t))
     assert torch.equal(psch.estimate_variance_t(D(t), 4).cpu(), osch.estimate_variance_t(t, 4))
+    # scheduler_base.py:20-24 sample(): random t per row, x_T ~ N(0, 1), x_t from the forward process -- consistent with the pieces above
+    x_t, x_T, ts = psch.sample(D(x0))
+    assert ts.shape == (5,) and ts.dtype == torch.long and int(ts.min()) >= 0 and int(ts.max()) < psch.T
+    assert x_T.shape == x0.shape and bool(x_T.isfinite().all()) and 0.5 < float(x_T.std()) < 1.5
+    assert torch.equal(x_t.cpu(), osch.estimate_x_t(x0, ts.cpu(), x_T.cpu()))
 
 
 def test_image_egress_uint8(dev):
