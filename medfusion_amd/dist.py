@@ -26,7 +26,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("MEDFUSION_FORCE_COLLECTIVE", "0") == "1"   # a 1-rank group too: the collective path on the hardware at hand
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -37,8 +38,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 def gather_images(local: torch.Tensor, num_samples: int, rank: int, world: int) -> torch.Tensor:
     """All-gather the per-rank image shards [B_r, C, H, W] into the global [num_samples, C, H, W] (row order = sample index).
-    Shards may differ by one row; they are padded to the largest and trimmed after the collective."""
-    if world == 1:
+    Shards may differ by one row; they are padded to the largest and trimmed after the collective.
+    world == 1 returns the shard as it is -- unless MEDFUSION_FORCE_COLLECTIVE=1 and a process group exists: then the 1-rank group runs
+    the same all-gather (on device memory over RCCL when the backend is nccl), which is how the collective path is exercised on a
+    single-GPU box (tests/test_multiproc_gpu.py::test_rccl_world1_device_allgather)."""
+    if world == 1 and not (os.environ.get("MEDFUSION_FORCE_COLLECTIVE", "0") == "1" and dist.is_initialized()):
         return local
     sizes = [shard_rows(num_samples, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)

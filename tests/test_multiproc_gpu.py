@@ -91,6 +91,56 @@ def test_two_ranks_two_gpus_rccl(tmp_path):
     _launch("nccl", 2, 2, tmp_path)
 
 
+RCCL1 = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+os.environ["MEDFUSION_FORCE_COLLECTIVE"] = "1"
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1")
+import torch.distributed as dist
+import medfusion_amd as M
+from medfusion_amd import dist as D
+rank, local, world = D.init_from_env("nccl")           # a ONE-rank RCCL communicator on device 0
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", 0)
+x = torch.arange(5 * 3 * 8 * 8, dtype=torch.float32, device=dev).reshape(5, 3, 8, 8) * 0.5 - 7.0
+out = D.gather_images(x, 5, 0, 1)                       # all_gather on device memory through RCCL (no early return)
+torch.cuda.synchronize()
+assert out.is_cuda and out.data_ptr() != x.data_ptr() and torch.equal(out, x)
+# the library's own output through the same path: a tiny sample() gathered by the 1-rank group equals the un-gathered one
+from medfusion_amd import published as P
+from medfusion_amd.unet import UNet, TimeEmbbeding
+ukw = dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[32, 32, 64, 64], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], time_embedder=TimeEmbbeding,
+           time_embedder_kwargs={{"emb_dim": 64}}, cond_embedder=None, deep_supervision=False, use_res_block=True, use_attention="none")
+pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, UNet, None, P.published_scheduler_kwargs(), ukw, estimator_objective="x_T", clip_x0=False)
+P.seeded_fill(pipe.noise_estimator, "mp1.unet.")
+pipe.to(dev).eval()
+a = D.sample_sharded(pipe, 3, (8, 8, 8), noise=M.PhiloxDeviceNoise(5), steps=2, use_ddim=True)
+b = pipe.sample(3, (8, 8, 8), noise=M.PhiloxDeviceNoise(5), steps=2, use_ddim=True)
+assert torch.equal(a, b)
+t = torch.ones(1 << 20, device=dev)
+dist.all_reduce(t)                                      # (one more collective of the same communicator, 4 MB)
+torch.cuda.synchronize()
+assert float(t.sum()) == float(1 << 20)
+print("RCCL1_OK", "rccl", ".".join(str(v) for v in torch.cuda.nccl.version()), flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_world1_device_allgather(tmp_path):
+    """RCCL executed on the hardware at hand: a ONE-rank nccl (= RCCL) process group on device 0, the gather of
+    dist.gather_images on DEVICE tensors through it (MEDFUSION_FORCE_COLLECTIVE=1 removes the world == 1 early return), a sharded
+    sample() through the same call, and an all-reduce on the same communicator.  No scaling number -- the transport, the communicator
+    set-up and the device-memory path of the gather run for real."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(RCCL1.format(root=str(ROOT)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, str(script)], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL1_OK" in r.stdout, r.stdout[-2000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
 def test_bench_launches_its_own_ranks_or_refuses_loudly(tmp_path):
     """`python bench.py --gpus N` (no launcher around it): N ranks under torch.distributed.run when N devices exist, else exit code 2
     with a message -- never a silent 1-GPU run labelled otherwise."""

@@ -27,6 +27,23 @@ def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def relerr_rows(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max over the samples (leading axis) of the PER-SAMPLE max-norm relative error max|a_n - b_n| / max|b_n|: the whole-tensor figure of
+    `relerr` divides by the largest sample of the batch, so an error confined to a small-magnitude sample hides behind a large one
+    (VERDICT r03, weak 1)."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    return float(((a - b).abs().amax(1) / b.abs().amax(1).clamp_min(1e-30)).max())
+
+
+def relerr_rms(a: torch.Tensor, b: torch.Tensor) -> float:
+    """max over the samples of the per-sample RMS-relative error sqrt(mean (a_n - b_n)^2 / mean b_n^2): an error spread over many small
+    elements shows here although no single element moves the max norm."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    return float(((a - b).pow(2).mean(1) / b.pow(2).mean(1).clamp_min(1e-60)).sqrt().max())
+
+
 def to_product_kwargs(kw: dict) -> dict:
     """oracle kwargs -> product kwargs (swap the embedder classes)."""
     import medfusion_amd as M
