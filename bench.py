@@ -152,6 +152,24 @@ def cpu_baseline(classes):
         t0 = time.perf_counter()
         vae.decode(z)
         t_dec = time.perf_counter() - t0
+        # SURVEY 8(d) says os.cpu_count() threads: measured here on ONE UNet forward at B=1, next to the same forward on `threads` (bounded: the
+        # all-threads run was 50x slower in round 1 -- ATen's CPU convolutions oversubscribe -- which is why the baseline above uses `threads`)
+        t1 = torch.full((1,), 500)
+        unet(z, t1)
+        t0 = time.perf_counter()
+        unet(z, t1)
+        t_b1 = time.perf_counter() - t0
+        all_threads = None
+        if ncpu > threads:
+            torch.set_num_threads(ncpu)
+            unet(z, t1)
+            t0 = time.perf_counter()
+            unet(z, t1)
+            t_b1_all = time.perf_counter() - t0
+            torch.set_num_threads(threads)
+            all_threads = {"threads": ncpu, "unet_b1_seconds": round(t_b1_all, 4), f"unet_b1_seconds_at_{threads}_threads": round(t_b1, 4),
+                           "slowdown_vs_baseline_threads": round(t_b1_all / t_b1, 2),
+                           "what": f"one published-UNet forward at B=1 on all {ncpu} logical CPUs vs on {threads}: the reason cpu_baseline.cores is {threads}, not os.cpu_count()"}
         # BASELINE.json configs[0] timed IN FULL: 64x64 images = latent (8, 8, 8), B=2, unconditional, 50 DDIM iterations + decode
         pipe = R.DiffusionPipeline(noise_scheduler=R.GaussianNoiseScheduler(**R.published_scheduler_kwargs()), noise_estimator=unet, latent_embedder=vae,
                                    estimator_objective="x_T", clip_x0=False)
@@ -164,6 +182,7 @@ def cpu_baseline(classes):
     return {"value": round(ips, 5), "unit": "images/s", "cores": threads, "host_logical_cpus": ncpu, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle (CPU restatement of the reference, torch fp32, {threads} threads of {ncpu} logical CPUs): 3 UNet forwards at B=4 "
                       f"({t_unet:.3f} s each) + 1 VAE decode at B=1 ({t_dec:.3f} s), extrapolated to 150 iterations x 4 images",
+            "all_threads": all_threads,
             "cfg1_full": {"value": round(2.0 / t_cfg1, 4), "unit": "images/s", "seconds": round(t_cfg1, 2),
                           "what": "BASELINE configs[0] run in full on the same threads: 2 unconditional 64x64 images (latent 8x8x8), 50 DDIM iterations + VAE "
                                   "decode, published architecture"}}
@@ -180,7 +199,11 @@ def pmc_traffic(match):
             top = max(cand, key=lambda e: e.get("launches", 0))
             n = sum(e["launches"] for e in cand)
             avg = sum(e["launches"] * e["hbm_bytes_per_launch"] for e in cand) / n
+            from medfusion_amd.build import conv_source_stamp
+            stamp = pj.get("conv_source_stamp")
             return int(avg), {"file": "profiles/pmc_bench_traffic.json", "command": pj.get("command"), "method": pj["method"], "launches_profiled": n,
+                              "conv_source_stamp_of_the_profile": stamp, "conv_source_stamp_now": conv_source_stamp(),
+                              "stale": stamp != conv_source_stamp(),
                               "most_frequent_tile": {"kernel": top["kernel"][:80], "launches": top["launches"],
                                                      "hbm_bytes_per_launch": top["hbm_bytes_per_launch"]}}
     except (OSError, KeyError, ValueError):
@@ -203,6 +226,7 @@ def main():
                     help="arithmetic of the conv kernel (MF_CONV_*): see ARITH in this file; 4 is the opt-in REDUCED precision mode, never the headline")
     ap.add_argument("--alt-precision", type=int, default=None, choices=sorted(ARITH), help="also time the same step on this arithmetic (default: the other fp32-class ones)")
     ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed steps on the other conv arithmetics")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the other BASELINE.json configs (cfg3 g=1 / g=8, cfg4, cfg5) that a default cfg2 run also times")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -315,6 +339,7 @@ def main():
                 "executed_over_algorithmic": round(ex / fl, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per conv launch, launch-weighted average over the tile instantiations (PMC)",
                 "traffic_from_committed_profile": True,   # PMC counters cannot be read inside this process: NOT measured in this run
+                "traffic_stale": None if traffic_src is None else traffic_src["stale"],   # the conv sources / tile table changed since the PMC passes
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes / n),   # operands read once + output written once (fp32 sizes), same average
                 "launches": int(n), "avg_launch_ms": round(ms / n, 5), "share_of_gpu_time": round(ms / total_ms, 4),
@@ -330,6 +355,38 @@ def main():
             dta = timed(max(1, args.steps)) / max(1, args.steps)
             alts.append({"conv_precision": a, "arithmetic": ARITH[a]["text"], "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)})
         BLK.CONV_PRECISION = prec
+    others_wl = []
+    if (not args.no_other_workloads and rank == 0 and world == 1 and args.workload == "cfg2" and not args.ddim_steps and not args.batch
+            and args.conv_precision is None):
+        # every other BASELINE.json config at its per-GPU size, in THIS process and on the default arithmetic: a warm-up
+        # (short for cfg4: its loop is the 1000-iteration one), then the timed steps, fenced like the headline.  ~15 s in all.
+        pipes = {None: pipe}
+        for name, nsteps in (("cfg3_g1", 2), ("cfg3_g8", 2), ("cfg5", 2), ("cfg4", 1)):
+            w2 = WORKLOADS[name]
+            if w2["classes"] not in pipes:
+                pipes[w2["classes"]] = P.build_published_pipeline(dev, w2["classes"])
+            p2 = pipes[w2["classes"]]
+            c2 = (torch.arange(w2["batch"], device=dev) % w2["classes"]) if w2["classes"] else None
+            k2 = dict(use_ddim=w2["use_ddim"])
+            if c2 is not None:
+                k2.update(guidance_scale=w2["guidance"], un_cond=None)
+            p2.sample(w2["batch"], w2["latent"], condition=c2, noise=M.PhiloxDeviceNoise(3000), steps=min(w2["steps"], 20), **k2)   # warm-up
+            if name != "cfg4":
+                p2.sample(w2["batch"], w2["latent"], condition=c2, noise=M.PhiloxDeviceNoise(3001), steps=w2["steps"], **k2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(nsteps):
+                img2 = p2.sample(w2["batch"], w2["latent"], condition=c2, noise=M.PhiloxDeviceNoise(3100 + k), steps=w2["steps"], **k2)
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t0) / nsteps
+            assert img2.shape[0] == w2["batch"] and bool(torch.isfinite(img2).all())
+            others_wl.append({"workload": name, "value": round(w2["batch"] / d2, 4), "unit": "images/s", "steps": nsteps, "ms_per_step": round(d2 * 1e3, 2),
+                              "config": {"workload": f"{name}: {w2['batch']} images/GPU, latent {w2['latent']}, {w2['steps']} {'DDIM' if w2['use_ddim'] else 'DDPM'} "
+                                                     f"iterations, {'uncond' if c2 is None else 'cond %d-class g=%s' % (w2['classes'], w2['guidance'])}, decode to "
+                                                     f"{8 * w2['latent'][1]}x{8 * w2['latent'][2]}", "n_gpus": 1,
+                                         "baseline_config": {"cfg3_g1": "configs[2] per-GPU share (128 / 8), guidance 1", "cfg3_g8": "configs[2] per-GPU share, guidance 8 (2B-row UNet calls)",
+                                                             "cfg4": "configs[3]", "cfg5": "configs[4] per-GPU share (32 / 4)"}[name]}})
+        del pipes
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(wl["classes"])
@@ -350,6 +407,8 @@ def main():
         }
         if alts:
             out["other_conv_arithmetic"] = alts
+        if others_wl:
+            out["other_workloads"] = others_wl
         if gflop_img:
             out["whole_path_algorithmic_tflops_per_gpu"] = round(ips / world * gflop_img / 1e3, 2)
             out["whole_path_x_over_fp32_peak"] = round(ips / world * gflop_img / 1e3 / PEAK_FP32_TFLOPS, 4)   # (a ratio, see roofline.x_over_...)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 210 /* 0.2.1 */
+#define MF_VERSION 220 /* 0.2.2 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -202,6 +202,11 @@ int mf_linear_f32(const float* x, int64_t x_stride, const float* w, const float*
  * freqs: optional device table f_k[half] precomputed by the host exactly like the reference (a 1-ulp difference
  * in f_k is amplified by t ~ 1000); NULL = compute with device expf. */
 int mf_sinusoidal_f32(const float* t, const float* freqs, float* out, int B, int dim, float max_period, float shift, int flip, void* stream);
+/* LearnedSinusoidalPosEmb (ABI 220; time_embedder.py:31-49): out[b] = [t_b | sin(2 pi t_b w_k) | cos(2 pi t_b w_k) | 0 if emb_dim is odd],
+ * k < emb_dim / 2, row length 1 + 2 (emb_dim / 2) + (emb_dim & 1); the angle is formed in the reference's order ((t w) 2) pi in fp32.
+ * (The reference's TimeEmbbeding cannot hold this embedder -- its first Linear takes emb_dim features, this returns emb_dim + 1 -- so it
+ * is a stand-alone module there and here.) */
+int mf_learned_sinusoidal_f32(const float* t, const float* weights, float* out, int B, int emb_dim, void* stream);
 /* LabelEmbedder lookup + save_add (cond_embedders.py:19-24, conv_blocks.py:16-18): io[b][:] += table[idx[b]][:] */
 int mf_embedding_add_f32(const float* table, const int64_t* idx, float* io, int B, int D, int num_rows, void* stream);
 

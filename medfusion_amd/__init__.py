@@ -8,7 +8,7 @@ from .lib import load as load_library  # noqa: F401
 from .noise import HostNoise, NoiseSource, PhiloxDeviceNoise, torch_cpu_noise  # noqa: F401
 from .pipeline import DiffusionPipeline, EMAModel  # noqa: F401
 from .scheduler import BasicNoiseScheduler, GaussianNoiseScheduler  # noqa: F401
-from .unet import LabelEmbedder, SinusoidalPosEmb, TimeEmbbeding, UNet  # noqa: F401
+from .unet import LabelEmbedder, LearnedSinusoidalPosEmb, SinusoidalPosEmb, TimeEmbbeding, UNet  # noqa: F401
 from .vae import VAE, DiagonalGaussianDistribution  # noqa: F401
 
 __version__ = "0.1.0"

@@ -23,6 +23,7 @@ _CLASS_MAP = {
     "UNet": ("medfusion_amd.unet", "UNet"),
     "TimeEmbbeding": ("medfusion_amd.unet", "TimeEmbbeding"),
     "SinusoidalPosEmb": ("medfusion_amd.unet", "SinusoidalPosEmb"),
+    "LearnedSinusoidalPosEmb": ("medfusion_amd.unet", "LearnedSinusoidalPosEmb"),
     "LabelEmbedder": ("medfusion_amd.unet", "LabelEmbedder"),
     "GaussianNoiseScheduler": ("medfusion_amd.scheduler", "GaussianNoiseScheduler"),
     "VAE": ("medfusion_amd.vae", "VAE"),

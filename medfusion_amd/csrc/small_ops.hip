@@ -91,6 +91,23 @@ __global__ void sinusoidal_kernel(const float* __restrict__ t, const float* __re
   out[i] = v;
 }
 
+// LearnedSinusoidalPosEmb (time_embedder.py:31-49): out[b] = [t_b | sin(a_bk) | cos(a_bk) | 0 if emb_dim is odd], a_bk = ((t_b w_k) 2) pi in the
+// reference's left-to-right fp32 order (`x * w * 2 * math.pi`), k < half = emb_dim / 2; row length 1 + 2 half + (emb_dim & 1)
+__global__ void learned_sinusoidal_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int B, int half, int row) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * row) return;
+  const int b = i / row, j = i - b * row;
+  float v = 0.f;
+  if (j == 0) v = t[b];
+  else if (j <= 2 * half) {
+    const int k = (j - 1) < half ? j - 1 : j - 1 - half;
+    const float a = ((t[b] * w[k]) * 2.0f) * 3.14159265358979323846f;
+    v = (j - 1) < half ? sinf(a) : cosf(a);
+  }
+  out[i] = v;
+}
+
 __global__ void embedding_add_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, float* __restrict__ io, int B, int D,
                                      int rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,6 +215,15 @@ int mf_sinusoidal_f32(const float* t, const float* freqs, float* out, int B, int
   ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * B * dim);
   MF_LAUNCH(sinusoidal_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, s, t, freqs, out, B, dim, coef, flip);
   return check_launch("sinusoidal");
+}
+
+int mf_learned_sinusoidal_f32(const float* t, const float* weights, float* out, int B, int emb_dim, void* stream) {
+  MF_REQUIRE(t && weights && out && B > 0 && emb_dim > 1, MF_EINVAL, "learned_sinusoidal: bad args");
+  const int half = emb_dim / 2, row = 1 + 2 * half + (emb_dim & 1);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_MISC, s, 0, 4.0 * B * row);
+  MF_LAUNCH(learned_sinusoidal_kernel, dim3((B * row + 255) / 256), dim3(256), 0, s, t, weights, out, B, half, row);
+  return check_launch("learned_sinusoidal");
 }
 
 int mf_embedding_add_f32(const float* table, const int64_t* idx, float* io, int B, int D, int num_rows, void* stream) {

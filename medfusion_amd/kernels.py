@@ -504,6 +504,16 @@ def sinusoidal(t: torch.Tensor, dim: int, max_period: float = 10000.0, shift: fl
     return out
 
 
+def learned_sinusoidal(t: torch.Tensor, weights: torch.Tensor, emb_dim: int) -> torch.Tensor:
+    """LearnedSinusoidalPosEmb.forward (time_embedder.py:42-49): [B] -> [B, 1 + 2 (emb_dim // 2) + (emb_dim & 1)]"""
+    _gpu(t, weights)
+    t = t.to(torch.float32).contiguous()
+    w = weights.detach().contiguous()
+    out = torch.empty((t.shape[0], 1 + 2 * (emb_dim // 2) + (emb_dim & 1)), dtype=torch.float32, device=t.device)
+    L.check(L.load().mf_learned_sinusoidal_f32(t.data_ptr(), w.data_ptr(), out.data_ptr(), t.shape[0], emb_dim, stream()), "mf_learned_sinusoidal_f32")
+    return out
+
+
 def embedding_add(table: torch.Tensor, idx: torch.Tensor, io: torch.Tensor) -> torch.Tensor:
     _gpu(table, idx, io)
     idx = idx.to(torch.int64).contiguous()

@@ -72,6 +72,7 @@ _SIGS = {
     "mf_gn_apply_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I64, c_fp, _I, _I, _I, _I, _I, c_fp]),
     "mf_linear_f32": (_I, [c_fp, _I64, c_fp, c_fp, c_fp, _I64, _I, _I, _I, _I, _I, _I, c_fp]),
     "mf_sinusoidal_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _F, _F, _I, c_fp]),
+    "mf_learned_sinusoidal_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, c_fp]),
     "mf_embedding_add_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
     "mf_sched_step_f32": (_I, [C.POINTER(MfSchedArgs), c_fp]),
     "mf_broadcast_from_table_f32": (_I, [c_fp, c_fp, C.c_int32, c_fp, _I, c_fp]),

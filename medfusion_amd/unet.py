@@ -38,6 +38,20 @@ class SinusoidalPosEmb(nn.Module):
                             freqs=self.freqs(x.device))
 
 
+class LearnedSinusoidalPosEmb(nn.Module):
+    """time_embedder.py:31-49: [x | sin(2 pi x w) | cos(2 pi x w)] with the learned frequency vector `weights` [emb_dim // 2] (same key).
+    The row has emb_dim + 1 features (even emb_dim; odd: emb_dim + 1 after the zero pad), so -- as in the reference, whose first Linear
+    raises on it -- TimeEmbbeding cannot hold this embedder; it is a stand-alone module."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.weights = nn.Parameter(torch.randn(emb_dim // 2))
+
+    def forward(self, x):
+        return K.learned_sinusoidal(x, self.weights, self.emb_dim)
+
+
 class TimeEmbbeding(nn.Module):
     """time_embedder.py:52-75: sinusoid(emb_dim//4) -> Linear -> Swish -> Linear (keys time_emb.1.*, time_emb.3.*)."""
 
@@ -53,6 +67,8 @@ class TimeEmbbeding(nn.Module):
     def forward(self, time):
         s = self.pos_embedder(time)
         l1, l2 = self.time_emb[1], self.time_emb[3]
+        if s.shape[1] != l1.in_features:   # (LearnedSinusoidalPosEmb: emb_dim + 1 features -- the reference's nn.Linear raises the same way)
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({s.shape[0]}x{s.shape[1]} and {l1.in_features}x{l1.out_features})")
         h = K.linear(s, l1.weight, l1.bias, act_out=True)
         return K.linear(h, l2.weight, l2.bias)
 

@@ -36,6 +36,7 @@ from medical_diffusion.models.estimators import UNet as RefUNet
 from medical_diffusion.models.noise_schedulers import GaussianNoiseScheduler as RefScheduler
 from medical_diffusion.models.embedders.latent_embedders import VAE as RefVAE
 from medical_diffusion.models.embedders import LabelEmbedder as RefLabel, TimeEmbbeding as RefTime, SinusoidalPosEmb as RefSin
+from medical_diffusion.models.embedders.time_embedder import LearnedSinusoidalPosEmb as RefLearned
 from medical_diffusion.models.utils import conv_blocks as RC
 from medical_diffusion.models.utils import attention_blocks as RA
 
@@ -131,6 +132,29 @@ def case_embedders():
     c = torch.tensor([2, 0, 1, 1])
     check_equal("label", rl(c), ol(c))
     save("embedders", t_sin=t, sin20=a, t_long=tt, time64=ea, t_float=tf, time64_float=fa, cond=c, label64=rl(c))
+
+
+@torch.no_grad()
+def case_learned_posemb():
+    """time_embedder.py:31-49 (round 4): even and odd emb_dim, integer-valued and fractional timesteps; and the fact that the reference's
+    TimeEmbbeding cannot hold this embedder (its first Linear takes emb_dim features, the embedder returns emb_dim + 1)."""
+    out = {}
+    for e in (16, 33):
+        ref, ora = RefLearned(e), R.LearnedSinusoidalPosEmb(e)
+        synth_pair(ref, ora, f"learned{e}.")
+        t = torch.tensor([0.0, 1.0, 0.37, 17.5, 999.0])
+        a, b = ref(t), ora(t)
+        check_equal(f"learned{e}", a, b)
+        out[f"y{e}"] = a
+        out[f"w{e}"] = ref.weights.detach()
+        out["t"] = t
+    raised = False
+    try:
+        RefTime(emb_dim=64, pos_embedder=RefLearned, pos_embedder_kwargs={"emb_dim": 16})(torch.tensor([1.0, 2.0]))
+    except RuntimeError:
+        raised = True
+    assert raised, "the reference's TimeEmbbeding accepted LearnedSinusoidalPosEmb: the product's refusal would be wrong"
+    save("learned_posemb", **out)
 
 
 @torch.no_grad()
@@ -394,7 +418,7 @@ def case_cfg1_published():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    cases = [case_scheduler, case_embedders, case_blocks, case_nonlearnable, case_use_res, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
+    cases = [case_scheduler, case_embedders, case_learned_posemb, case_blocks, case_nonlearnable, case_use_res, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
     for fn in cases:
         if only and fn.__name__ not in only:
             continue

@@ -375,6 +375,26 @@ class SinusoidalPosEmb(nn.Module):
         return e
 
 
+class LearnedSinusoidalPosEmb(nn.Module):
+    """time_embedder.py:31-49: [x | sin(2 pi x w) | cos(2 pi x w)] with a learned frequency vector `weights` [emb_dim // 2]; the output has
+    emb_dim + 1 features for an even emb_dim and emb_dim + 1 (zero-padded) for an odd one -- which is why the reference's own
+    TimeEmbbeding(pos_embedder=LearnedSinusoidalPosEmb) raises in its first Linear (checked against the reference in gen_golden.py)."""
+
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.emb_dim = emb_dim
+        self.weights = nn.Parameter(torch.randn(emb_dim // 2))
+
+    def forward(self, x):
+        x = x[:, None]
+        freqs = x * self.weights[None, :] * 2 * math.pi
+        f = torch.cat((freqs.sin(), freqs.cos()), dim=-1)
+        f = torch.cat((x, f), dim=-1)
+        if self.emb_dim % 2 == 1:
+            f = F.pad(f, (0, 1, 0, 0))
+        return f
+
+
 class TimeEmbbeding(nn.Module):
     """sinusoid(emb_dim//4) -> Linear -> Swish -> Linear.  time_embedder.py:52-75.
     (Implements the intended `pos_emb_dim = emb_dim // 4` rule; the reference's mutable

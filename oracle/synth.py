@@ -162,6 +162,8 @@ def _kind_of(key: str, shape) -> str:
         return "gamma" if len(shape) == 1 else "weight"
     if leaf == "bias":
         return "bias"
+    if leaf == "weights" and len(shape) == 1:   # LearnedSinusoidalPosEmb's frequency vector (time_embedder.py:39): randn-like spread
+        return "embedding"
     raise ValueError(f"unexpected parameter {key}")
 
 

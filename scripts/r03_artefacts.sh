@@ -6,7 +6,7 @@ set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z
 mkdir -p $O/prof
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-path --no-roofline > $O/prof_bench.json 2> $O/prof_bench.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-path --no-roofline --no-other-workloads > $O/prof_bench.json 2> $O/prof_bench.err
 python $R/scripts/trace_gaps.py $O/prof/bench_kernel_trace.csv $O/trace_gaps.txt | head -12
 cp $O/prof/bench_kernel_stats.csv $O/kernel_stats.csv
 rm -f $O/prof/bench_kernel_trace.csv $O/prof/*agent_info* $O/prof/*domain_stats*

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
-    assert lib.mf_version() == 210
+    assert lib.mf_version() == 220
     assert lib.mf_prof_family_name(0) == b"conv_igemm"
 
 

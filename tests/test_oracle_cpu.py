@@ -62,6 +62,18 @@ def test_embedders():
     assert torch.equal(le(T(g["cond"])), T(g["label64"]))
 
 
+@torch.no_grad()
+def test_learned_sinusoidal_posemb():
+    """time_embedder.py:31-49 against the reference's own output (even and odd emb_dim): the first column is t itself, bit for bit"""
+    g = gold("learned_posemb")
+    for e in (16, 33):
+        m = R.LearnedSinusoidalPosEmb(e)
+        S.synth_state_dict(m, f"learned{e}.")
+        assert torch.equal(m.weights.detach(), T(g[f"w{e}"]))
+        y = m(T(g["t"]))
+        assert y.shape == (5, e + 1) and torch.equal(y[:, 0], T(g["t"])) and relerr(y, T(g[f"y{e}"])) <= TOL
+
+
 GN32 = ("GROUP", {"num_groups": 32, "affine": True})
 GN8 = ("GROUP", {"num_groups": 8, "affine": True})
 

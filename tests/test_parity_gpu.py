@@ -144,6 +144,27 @@ def test_embedders_golden(dev):
     assert torch.equal(le.to(dev)(T(g["cond"]).to(dev)).cpu(), T(g["label64"]))
 
 
+def test_learned_sinusoidal_posemb_golden(dev, conv_precision):
+    """LearnedSinusoidalPosEmb (time_embedder.py:31-49) against the reference's output; and TimeEmbbeding refuses it the way the reference's
+    first nn.Linear does (emb_dim + 1 features into Linear(emb_dim, ...))"""
+    if conv_precision != 5:
+        pytest.skip("runs once")
+    g = gold("learned_posemb")
+    for e in (16, 33):
+        m = M.LearnedSinusoidalPosEmb(e)
+        S.synth_state_dict(m, f"learned{e}.")
+        y = m.to(dev)(T(g["t"]).to(dev))
+        assert y.shape == (5, e + 1) and torch.equal(y[:, 0].cpu(), T(g["t"]))
+        # the angle 2 pi t w reaches ~6e3 rad: one fp32 ulp of it is 5e-4, so sin / cos agree with ATen's to that absolute level, not to 1e-6
+        assert float((y.cpu() - T(g[f"y{e}"])).abs().max()) < 2e-3
+        small = T(g["t"])[:3]                                  # |angle| < ~10: sinf / cosf agree to a few ulp
+        ys = m(small.to(dev)).cpu()
+        assert float((ys - T(g[f"y{e}"])[:3]).abs().max()) < 1e-5
+    te = M.TimeEmbbeding(64, pos_embedder=M.LearnedSinusoidalPosEmb, pos_embedder_kwargs={"emb_dim": 16}).to(dev)
+    with pytest.raises(RuntimeError, match="shapes cannot be multiplied"):
+        te(torch.tensor([1.0, 2.0], device=dev))
+
+
 @pytest.mark.parametrize("tag", list(UNET_CASES))
 def test_unet_tiny_golden(dev, tag):
     g = gold(f"unet_tiny_{tag}")
