@@ -285,6 +285,7 @@ class BasicResBlock(nn.Module):
         super().__init__()
         self.basic_block = BasicBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, act_name, dropout, zero_conv)
         self.conv_res = Conv(in_channels, out_channels, 1, stride, monai_padding(1, stride)) if in_channels != out_channels else nn.Identity()
+        self._pairs_ok = {}
 
     def forward(self, x: Act, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_fp32=True):
         """out_fp32=False: the caller promises that the block's output is read by fp16-pair convolutions and residual adds only"""
@@ -295,11 +296,19 @@ class BasicResBlock(nn.Module):
         res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
         return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
 
-    def reads_pairs_only(self) -> bool:
-        """can this block take an input that exists as fp16 pairs only?  Its convolutions must be on the fp16-pair kernel (its residual add
-        reads pairs anyway)"""
-        convs = [self.basic_block.conv] + ([] if isinstance(self.conv_res, nn.Identity) else [self.conv_res])
-        return f16x2_mode() and hasattr(self.basic_block, "norm") and all(c.in_ch % 32 == 0 and c.out_ch % 64 == 0 for c in convs)
+    def reads_pairs_only(self, n: int, h: int, w: int) -> bool:
+        """can this block take an [n, h, w, Cin] input that exists as fp16 pairs only?  Its convolutions must be on the fp16-pair kernel FOR
+        THAT SHAPE (its residual add reads pairs anyway): asked of the planner itself (mf_conv2d_f16x2_ok on the real descriptor -- tensor
+        size limits, tile fits -- not guessed from channel counts: ADVICE r03), cached per shape"""
+        if not (f16x2_mode() and hasattr(self.basic_block, "norm")):
+            return False
+        key = (n, h, w, CONV_PRECISION)
+        ok = self._pairs_ok.get(key)
+        if ok is None:
+            convs = [self.basic_block.conv] + ([] if isinstance(self.conv_res, nn.Identity) else [self.conv_res])
+            ok = all(K.conv_f16x2_ok(K.make_conv_desc(n, h, w, c.in_ch, 0, c.out_ch, c.k, c.stride, c.pad, 0, precision=CONV_PRECISION)) for c in convs)
+            self._pairs_ok[key] = ok
+        return ok
 
 
 class _EmbBlock(nn.Module):
@@ -330,8 +339,15 @@ class _EmbBlock(nn.Module):
                 # the output of every block but the last is read by the NEXT block alone: its convolutions (fp16 pairs) and its residual
                 # add -- the fp32 form need not be written when that block can read pairs (12 instead of 16 bytes per element)
                 nxt = self.block_seq[i + 1] if i + 1 < n else None
-                x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC,
-                        out_fp32=not (PAIRS_ONLY_BETWEEN_BLOCKS and nxt is not None and nxt.reads_pairs_only()))
+                pairs_next = False
+                lay = in_layout if i == 0 else L.LAYOUT_NHWC
+                if PAIRS_ONLY_BETWEEN_BLOCKS and nxt is not None:
+                    x1 = _split(x)[0]
+                    nn_, hh, ww = (x1.shape[0], x1.shape[2], x1.shape[3]) if lay == L.LAYOUT_NCHW else (x1.shape[0], x1.shape[1], x1.shape[2])
+                    c0 = blk.basic_block.conv
+                    ho, wo = (hh + 2 * c0.pad - c0.k) // c0.stride + 1, (ww + 2 * c0.pad - c0.k) // c0.stride + 1   # shape of THIS block's output
+                    pairs_next = nxt.reads_pairs_only(nn_, ho, wo)
+                x = blk(x, emb=e, emb_stride=es, in_layout=lay, out_fp32=not pairs_next)
             else:
                 x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
         return x

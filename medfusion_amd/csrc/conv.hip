@@ -527,7 +527,8 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     return check_launch("conv_smallcin");
   }
   if (!pl.igemm && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->upsample == 0 && !p.in_nchw && d->C2 == 0 && d->Cout <= 8 &&
-      d->C1 % 32 == 0 && d->C1 / 32 <= 32 && ((d->C1 / 32) & (d->C1 / 32 - 1)) == 0) {
+      d->C1 % 32 == 0 && d->C1 / 32 <= 32 && ((d->C1 / 32) & (d->C1 / 32 - 1)) == 0 &&
+      (reinterpret_cast<uintptr_t>(x1) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {   // (float4 reads of x and w: else the generic kernel)
     ProfScope ps(MF_FAM_CONV_DIRECT, s, flops, bytes);
     const int lpp = d->C1 / 32;
     const long blocks = ((long)pl.M * lpp + 255) / 256;

@@ -39,6 +39,13 @@ def stream(device_index: Optional[int] = None) -> int:
     return (torch.cuda.current_stream() if device_index is None else torch.cuda.current_stream(device_index)).cuda_stream
 
 
+_growths = 0   # how often a Workspace / SyncWords buffer was (re)allocated: the command-list recorder compares before / after (pipeline.py)
+
+
+def scratch_growth_count() -> int:
+    return _growths
+
+
 class Workspace:
     """Grow-only scratch owned by torch (the library never allocates).  One per (device, stream): launches on one
     stream are serialised so sharing is safe.  Grown only outside graph capture (warm-up run does it)."""
@@ -54,6 +61,8 @@ class Workspace:
                 raise RuntimeError("medfusion_amd: workspace growth during graph capture; run one eager warm-up first")
             buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
             cls._bufs[key] = buf
+            global _growths
+            _growths += 1
         return buf
 
 
@@ -72,6 +81,8 @@ class SyncWords:
                 raise RuntimeError("medfusion_amd: sync-counter growth during graph capture; run one eager warm-up first")
             buf = torch.zeros(max(words, 1 << 14), dtype=torch.int32, device=device)
             cls._bufs[key] = buf
+            global _growths
+            _growths += 1
         return buf
 
     @classmethod
@@ -145,6 +156,11 @@ def stale(t: torch.Tensor) -> bool:
 def _fresh(t: torch.Tensor, name: str):
     """attribute `name` of t (a mirror), or None -- dropping every mirror first when a torch in-place op has touched t since they were made"""
     if stale(t):
+        if getattr(t, "_mf_pairs_only", False):
+            # the pairs are the ONLY valid copy of this tensor (its fp32 storage was never written): a torch in-place op on it has just
+            # modified garbage, and dropping the mirror would make every later reader take that garbage for the values (ADVICE r03)
+            raise RuntimeError("medfusion_amd: a torch in-place op touched a tensor that exists only as fp16 pairs (the output of a GroupNorm-apply "
+                               "pass between two convolutions); its fp32 storage holds no values")
         drop_split(t)
         t._mf_ver = None
     return getattr(t, name, None)
@@ -656,6 +672,7 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 def avgpool2d(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
     """nn.AvgPool2d(k, stride, pad) on NHWC (count_include_pad like torch's default)"""
     _gpu(x)
+    _need_f32(x)
     n, h, w, c = x.shape
     ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
@@ -666,6 +683,7 @@ def avgpool2d(x: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
 def upsample_nearest2x(x: torch.Tensor) -> torch.Tensor:
     """F.interpolate(scale 2, nearest-exact) on NHWC"""
     _gpu(x)
+    _need_f32(x)
     n, h, w, c = x.shape
     out = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
     L.check(L.load().mf_upsample_nearest2x_nhwc_f32(x.contiguous().data_ptr(), out.data_ptr(), n, h, w, c, stream()), "mf_upsample_nearest2x_nhwc_f32")

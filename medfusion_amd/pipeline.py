@@ -25,6 +25,10 @@ from .noise import NoiseSource, default_noise
 from .scheduler import GaussianNoiseScheduler
 
 
+_CMD_POOLS = {}       # device index -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from (process-wide)
+_GRAPH_STREAMS = {}   # device index -> the one side stream graph captures run on
+
+
 class _PureLaunchGuard(torch.utils._python_dispatch.TorchDispatchMode):
     """Active while the library records one loop iteration: notes every ATen operator that touches device memory other than allocation and
     metadata -- such work is not a launch of the library, so a replay of the recorded list would miss it."""
@@ -96,8 +100,8 @@ class DiffusionPipeline(nn.Module):
         self.clip_x0 = clip_x0
         self.batch_cfg = True  # classifier-free guidance as one 2B-row UNet call (same arithmetic per row)
         self.hoist_embeddings = True  # denoise(): time/label/local embeddings of all iterations evaluated once, before the loop
-        self._cmd_pools = {}          # device index -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from
-        self._graph_streams = {}      # device index -> the one side stream graph captures run on
+        # (the memory pools of the command-list loop and the capture streams live in module-level registries keyed by device, _CMD_POOLS /
+        # _GRAPH_STREAMS below: a torch.cuda.MemPool or Stream held by the nn.Module would break copy.deepcopy / pickling of the pipeline)
         self.last_cmdlist_launches = 0          # launches in the list the last command-list loop replayed (0: it ran eagerly)
         self.last_cmdlist_foreign_ops = []      # ATen operators that put device work into the recorded iteration (replay refused)
         self.time_cmdlist = False               # measurement aid: time the host side of one replayed iteration (costs a device sync)
@@ -368,20 +372,31 @@ class DiffusionPipeline(nn.Module):
             cur = K.stream(dev.index)
             first_iteration()
             if len(rev) > 1:
-                pool = self._cmd_pools.get(dev.index)
+                pool = _CMD_POOLS.get(dev.index)
                 if pool is None:
-                    pool = self._cmd_pools[dev.index] = torch.cuda.MemPool()
+                    pool = _CMD_POOLS[dev.index] = torch.cuda.MemPool()
                 handle = ctypes.c_void_p()
                 guard = _PureLaunchGuard()
-                with torch.cuda.use_mem_pool(pool, device=dev), guard:
-                    L.check(lib.mf_cmdlist_begin(), "mf_cmdlist_begin")
-                    try:
-                        keep = body()
-                    finally:
-                        L.check(lib.mf_cmdlist_end(ctypes.byref(handle)), "mf_cmdlist_end")
+                grew = K.scratch_growth_count()
+                try:
+                    with torch.cuda.use_mem_pool(pool, device=dev), guard:
+                        L.check(lib.mf_cmdlist_begin(), "mf_cmdlist_begin")
+                        try:
+                            keep = body()
+                        finally:
+                            L.check(lib.mf_cmdlist_end(ctypes.byref(handle)), "mf_cmdlist_end")
+                except BaseException:
+                    if handle:
+                        lib.mf_cmdlist_free(handle)   # (body() raised while recording: the list is dropped with it)
+                    raise
                 try:
                     self.last_cmdlist_launches = lib.mf_cmdlist_count(handle)
                     self.last_cmdlist_foreign_ops = sorted(set(guard.foreign))
+                    if K.scratch_growth_count() != grew:
+                        # the workspace or the split-K counters GREW during the recorded iteration (it needed more scratch than iteration 0):
+                        # launches recorded before the growth point at the released buffer -- the list is not replayable
+                        guard.foreign.append("medfusion_amd: scratch growth inside the recorded iteration")
+                        self.last_cmdlist_foreign_ops = sorted(set(guard.foreign))
                     if guard.foreign:
                         # torch itself put device work into the iteration (self-conditioning, an attention variant, ...): the recorded list
                         # is not the whole iteration -- drop it and run the remaining iterations through Python (same bits, host-bound)
@@ -403,9 +418,9 @@ class DiffusionPipeline(nn.Module):
                 del keep
             noise.draw_index = base + stride * len(rev)
             return
-        side = self._graph_streams.get(dev.index)      # ONE capture stream per device (per-stream workspaces / split-K counters stay bounded)
+        side = _GRAPH_STREAMS.get(dev.index)      # ONE capture stream per device (per-stream workspaces / split-K counters stay bounded)
         if side is None:
-            side = self._graph_streams[dev.index] = torch.cuda.Stream(device=dev)
+            side = _GRAPH_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             K.SyncWords.reset(dev)    # (the counters of THIS stream: _denoise reset those of the caller's stream)

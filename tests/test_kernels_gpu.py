@@ -166,6 +166,9 @@ def test_conv_split_bf16x3_wide_dynamic_range(dev):
     (2, 8, 8, 128, 5, 1, 1, "nhwc", "nhwc"),    # 4 lanes per pixel, Cout not a multiple of them, NHWC out
     (1, 5, 5, 1024, 2, 1, 1, "nhwc", "nchw"),   # 32 lanes per pixel
     (2, 8, 8, 96, 4, 1, 1, "nhwc", "nchw"),     # C / 32 not a power of two: the generic kernel
+    (2, 8, 8, 32, 3, 1, 1, "nhwc", "nchw"),     # conv_out1x1_kernel with ONE lane per pixel, Cout = 3, NCHW out
+    (1, 5, 5, 1024, 5, 1, 1, "nhwc", "nchw"),   # 32 lanes per pixel, Cout = 5, NCHW out
+    (3, 7, 5, 32, 5, 1, 1, "nhwc", "nhwc"),     # one lane per pixel, Cout = 5, NHWC out, ragged pixel count
 ])
 def test_conv_direct(dev, case):
     from medfusion_amd import kernels as K
