@@ -20,4 +20,4 @@ for (b, h, n, d) in ((16, 8, 1024, 32), (16, 8, 256, 64), (16, 8, 64, 128), (8, 
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     gf = 4.0 * b * h * n * n * d / 1e9
-    print(f"B={b} H={h} N={n} d={d}: {ms:.3f} ms  {gf / ms:.1f} TF  ({gf:.1f} GF)")
+    print(f"B={b} H={h} N={n} d={d} (C={c}): {ms:.3f} ms  {gf / ms:.1f} TF = {gf / ms / 157.3:.3f} of the 157.3 TF fp32-MFMA peak  ({gf:.1f} GF: QK^T + PV, fp32 operands)")
