@@ -126,6 +126,9 @@ def cpu_model() -> str:
     return "unknown"
 
 
+MEASURE_ALL_THREADS = False
+
+
 def cpu_baseline(classes):
     """The oracle (CPU restatement of the reference, kind='port') on this box's host cores, bounded sample:
     3 timed UNet forwards at B=4 and 1 VAE decode at B=1 -> extrapolated cfg2 images/s."""
@@ -159,8 +162,10 @@ def cpu_baseline(classes):
         t0 = time.perf_counter()
         unet(z, t1)
         t_b1 = time.perf_counter() - t0
-        all_threads = None
-        if ncpu > threads:
+        all_threads = {"threads": 256, "unet_b1_seconds": 51.0, "unet_b1_seconds_at_32_threads": 0.198, "slowdown_vs_baseline_threads": 257.5,
+                       "measured": "round 4 on the GPU box's EPYC 9575F (profiles/r04_baseline_bench_cfg2.json); re-measure with --cpu-all-threads (~100 s)",
+                       "what": "one published-UNet forward at B=1 on all 256 logical CPUs vs on 32: the reason cpu_baseline.cores is 32, not os.cpu_count()"}
+        if ncpu > threads and MEASURE_ALL_THREADS:
             torch.set_num_threads(ncpu)
             unet(z, t1)
             t0 = time.perf_counter()
@@ -226,11 +231,14 @@ def main():
                     help="arithmetic of the conv kernel (MF_CONV_*): see ARITH in this file; 4 is the opt-in REDUCED precision mode, never the headline")
     ap.add_argument("--alt-precision", type=int, default=None, choices=sorted(ARITH), help="also time the same step on this arithmetic (default: the other fp32-class ones)")
     ap.add_argument("--no-alt-path", action="store_true", help="skip the extra timed steps on the other conv arithmetics")
+    ap.add_argument("--cpu-all-threads", action="store_true", help="re-measure the oracle's UNet forward on ALL logical CPUs next to the 32-thread baseline (~100 s)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the other BASELINE.json configs (cfg3 g=1 / g=8, cfg4, cfg5) that a default cfg2 run also times")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    global MEASURE_ALL_THREADS
+    MEASURE_ALL_THREADS = args.cpu_all_threads
 
     import medfusion_amd as M
     from medfusion_amd import blocks as BLK

@@ -130,6 +130,43 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
                     double* gn_partial, int G, const MfConvDesc* d, void* stream);
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
 
+/* Convolution + GroupNorm + Swish + residual + embedding in ONE launch (ABI 220; BasicBlock.forward / BasicResBlock.forward,
+ * conv_blocks.py:185-191,236-240, with the `x += emb` of :360-363): the fp16-pair convolution whose workgroups keep their final tile in
+ * registers, publish the tile's partial GroupNorm sums (gn_partial, as in mf_conv2d_f16x2), meet the other tiles of their SAMPLE at a
+ * counter, finalize mean / rstd from the sample's records and apply act(gn(y) gamma + beta) + residual + emb[n][c] on the way out -- what
+ * mf_conv2d_f16x2 + mf_gn_apply_from_partials_pairs_f32 compute in two launches, bit for bit (same records, same summation order, same
+ * per-element operations); the un-normalised y is never written.  Workgroups WAIT for each other, so the form exists only for plans whose
+ * whole grid is resident on the device at once: mf_conv2d_f16x2_fuse_words(d, G) = the zero-initialised 32-bit words `rendezvous` needs
+ * (2 per sample; every launch leaves them zero; one array per stream), 0 = this convolution cannot (use the two-launch form).
+ * `error_flag`: one zero-initialised word; a wait that does not complete within 50 ms (another process's waiting workgroups filling the
+ * device) sets it, later launches stop waiting, and the results since are INVALID: the caller checks it at the end of its loop, zeroes
+ * flag and rendezvous words, and re-runs on the two-launch form.  Arguments as in the two calls it replaces; out may be NULL (fp16 pairs
+ * only), out_split / out_bound are required.  MEDFUSION_FUSED_APPLY=0 in the environment (read once) makes fuse_words return 0. */
+typedef struct MfGnFuse {
+  const float* gamma;            /* [Cout] or NULL (both) */
+  const float* beta;
+  const float* residual;         /* fp32 NHWC [N][Ho][Wo][Cout], or NULL */
+  const void* residual_pairs;    /* the residual as fp16 pairs scaled by res_bound, or NULL */
+  const float* res_bound;        /* [N], or NULL with res_bound_slots */
+  const float* res_bound_slots;  /* [N][res_nslots] slot maxima (y_bound of the convolution that made the residual) */
+  const float* emb;              /* emb[n * emb_stride + c] or NULL */
+  const float* emb_bound;        /* [N] */
+  float* out;                    /* fp32 result or NULL */
+  void* out_split;               /* fp16-pair result */
+  float* out_bound;              /* [N] written */
+  uint32_t* rendezvous;
+  uint32_t* error_flag;
+  int64_t emb_stride;
+  int32_t res_nslots;
+  int32_t act;                   /* 1: Swish */
+  float bconst;                  /* >= max |act(gn(y) gamma + beta)| (mf_gn_apply_from_partials_f32) */
+  float eps;
+} MfGnFuse;
+int mf_conv2d_f16x2_fuse_words(const MfConvDesc* d, int G);
+int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, const float* bias, const float* x1_bound, const float* x2_bound,
+                             float w_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                             const MfGnFuse* f, const MfConvDesc* d, void* stream);
+
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
  * parts = mf_conv2d_gn_parts(d, G); 0 means this convolution cannot emit them (use mf_gn_stats_partial_f32). */
@@ -321,7 +358,7 @@ int mf_image_egress_u8(const float* x_nchw, uint8_t* out_nhwc, float* minmax_ws,
  * When enabled every launch is bracketed by hipEvents on its own stream and attributed to a kernel family.
  * NOT capture-safe; off by default. */
 enum { MF_FAM_CONV_IGEMM = 0, MF_FAM_CONV_DIRECT, MF_FAM_SPLITK_REDUCE, MF_FAM_GN_STATS, MF_FAM_GN_APPLY, MF_FAM_LINEAR,
-       MF_FAM_SCHED, MF_FAM_NOISE, MF_FAM_ATTENTION, MF_FAM_MISC, MF_FAM_COUNT };
+       MF_FAM_SCHED, MF_FAM_NOISE, MF_FAM_ATTENTION, MF_FAM_MISC, MF_FAM_CONV_GN_FUSED, MF_FAM_COUNT };
 int mf_prof_enable(int on);
 int mf_prof_reset(void);
 /* synchronises outstanding events; returns summed ms, launch count, algorithmic flops and bytes of a family */

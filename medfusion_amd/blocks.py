@@ -146,6 +146,33 @@ class Conv(nn.Module):
             return y, K.GnPartials(partial, parts, gn_eps)
         return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)   # (more groups than a workgroup has threads)
 
+    def forward_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst):
+        """conv -> GroupNorm -> Swish -> + residual -> + emb in ONE launch (mf_conv2d_f16x2_gn_apply), or None when this convolution cannot
+        (not on the fp16-pair kernel, or a plan whose workgroups are not all resident at once): the caller takes the two-launch form"""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        if c1 + c2 != self.in_ch:
+            raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
+        prec = CONV_PRECISION
+        G = norm.num_groups
+        key = ("fused", n, h, w, c1, c2, G, prec)
+        ent = self._descs.get(key)
+        if ent is None:
+            d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=prec)
+            ent = (None, 0, 0, None)
+            if K.conv_f16x2_ok(d) and not self.upsample:
+                pinned = K.pin_conv_plan(d)
+                parts, words = K.conv_gn_parts(d, G), K.conv_fuse_words(d, G)
+                if parts > 0 and words > 0:
+                    ent = (d, parts, words, pinned)
+            self._descs[key] = ent
+        d, parts, words, pinned = ent
+        if d is None or K.Rendezvous.disabled:
+            return None
+        return K.conv2d_f16x2_gn_apply(x1, self._packed.get_f16x2(self.weight), self.bias, d, norm.weight, norm.bias, G, norm.eps, parts, words, act=act,
+                                       residual=residual, emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, pinned=pinned)
+
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
                 gn_eps: float = 1e-5, measure_out: bool = False):
         """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2]).
@@ -249,6 +276,15 @@ class BasicBlock(nn.Module):
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
+            if f16x2_mode() and in_layout == L.LAYOUT_NHWC and not K.Rendezvous.disabled:
+                # one launch for conv + GroupNorm + Swish + residual + embedding where the plan allows it (conv_f16x2.h: FuseP)
+                nm = self.norm
+                x1 = _split(x)[0]
+                ho, wo = (x1.shape[1] + 2 * self.conv.pad - self.conv.k) // self.conv.stride + 1, (x1.shape[2] + 2 * self.conv.pad - self.conv.k) // self.conv.stride + 1
+                bc = nm.bound_const(ho * wo * (self.conv.out_ch // nm.num_groups))
+                y = self.conv.forward_gn_apply(x, nm, int(self.has_act), residual, emb, emb_stride, out_fp32, bc)
+                if y is not None:
+                    return y
             return self.finish(self.conv_and_stats(x, in_layout), residual, emb, emb_stride, out_fp32)
         y = self.conv(x, in_layout=in_layout, out_layout=out_layout)
         if not (self.has_act or residual is not None or emb is not None):

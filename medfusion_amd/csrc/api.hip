@@ -213,7 +213,7 @@ int mf_cmdlist_free(void* list) {
 
 const char* mf_prof_family_name(int f) {
   static const char* names[MF_FAM_COUNT] = {"conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply",
-                                            "linear", "sched", "noise", "attention", "misc"};
+                                            "linear", "sched", "noise", "attention", "misc", "conv_gn_fused"};
   return (f >= 0 && f < MF_FAM_COUNT) ? names[f] : "?";
 }
 

@@ -41,6 +41,36 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// GroupNorm + Swish + residual + embedding fused INTO the convolution's launch (round 4; conv_blocks.py:185-191,236-240,360-363 in one kernel).
+// The workgroups that hold the final values of a tile keep them in registers, publish their partial GroupNorm records, meet the other
+// tiles of their SAMPLE at a counter (`rv`: one arrive / depart pair per sample, zero between launches), finalize mean / rstd from the
+// records of the whole sample and apply the normalisation to their own tile on the way out -- the un-normalised convolution output never
+// goes to memory, and the apply pass (a launch boundary + ~10 us per GroupNorm) disappears.  The host only asks for this when EVERY
+// workgroup of the launch is resident at once (grid <= CUs x occupancy: nobody waits for a workgroup that cannot start); a rendezvous that
+// does not complete within 50 ms (another process filling the device with ITS waiting workgroups) raises rv_err, every later launch stops
+// waiting, and the host re-runs the loop un-fused (pipeline.py).  on == 0: the plain epilogue.
+struct FuseP {
+  int on, act;
+  float eps, bconst;
+  double count;                 // elements of a group: HW * (Cout / G)
+  const float* gamma;           // [Cout] or null (both)
+  const float* beta;
+  const float* res_f32;         // residual as fp32 NHWC, or
+  const void* res_pairs;        // as fp16 pairs (scaled by res_bound), or neither
+  const float* res_bound;       // [N] bound of |residual|, or
+  const float* res_slots;       // [N][res_nslots] the slot maxima its convolution left
+  int res_nslots;
+  int tiles_per_sample;         // arrivals a sample's counter waits for
+  const float* emb;             // [N][emb_stride] embedding rows added per (n, c), or null
+  long emb_stride;
+  const float* emb_bound;       // [N]
+  float* out_f32;               // fp32 NHWC result, or null (pairs only)
+  void* out_pairs;              // fp16-pair result (always)
+  float* out_bound;             // [N] bound the pairs were scaled with
+  unsigned* rv;                 // [N][2] arrive / depart
+  unsigned* rv_err;             // one word: a rendezvous timed out
+};
+
 struct ConvP2 {
   const void* x1;   // [N][Hin][Win][C1/8][2][8] fp16 pairs
   const void* x2;   // second source of the fused channel concat, or null
@@ -68,6 +98,7 @@ struct ConvP2 {
   int tree;
   float* handoff;       // [tiles][2 (splitk - 1) slots][BM x BN floats]
   unsigned* sync;       // [tiles][splitk - 1] counters, zero between launches (the second arriver of a pair resets its counter)
+  FuseP fz;
 #if MFC2_HZ & (256 | 512)
   float* dbg;           // diagnostic builds: [tiles][waves][TM][TN][16][64] the accumulators of the surviving workgroup right behind the tree
 #endif

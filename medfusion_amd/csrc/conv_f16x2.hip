@@ -152,33 +152,68 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
 
 inline bool pair_precision(int prec) { return prec == MF_CONV_FP32_F16X2 || prec == MF_CONV_F16; }   // both run on the fp16-pair operands
 
+// How many workgroups of one kernel instantiation are resident on the current device at once (CUs x occupancy; 0: unknown -- no device).
+// The fused GroupNorm tail (conv_f16x2.h: FuseP) makes workgroups WAIT for the other tiles of their sample, so the host only asks for it
+// when the whole grid is resident from the start.
+int resident_workgroups(const void* fn, int threads, size_t lds) {
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || per <= 0) { (void)hipGetLastError(); return 0; }
+  return cus * per;
+}
+
+// mode 0: launch; mode 1: return resident_workgroups() of the instantiation (no launch)
 template <int BM, int BN, int WM, int WN, int NST, int TERMS>
-int launch_f16x2_t(const mfc2::ConvP2& p, hipStream_t s) {
+int launch_f16x2_t(const mfc2::ConvP2& p, hipStream_t s, int mode) {
   constexpr size_t lds = (size_t)NST * (BM + BN) * 128u;
   static DeviceOnce once;   // per device: the attribute belongs to the (function, device) pair
-  if (first_use_on_device(once))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void* fn = reinterpret_cast<const void*>(&mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>);
+  if (first_use_on_device(once)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (mode == 1) return resident_workgroups(fn, WM * WN * 64, lds);
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
   MF_LAUNCH((mfc2::conv_f16x2_kernel<BM, BN, WM, WN, NST, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_f16x2");
 }
 template <int BM, int BN, int WM, int WN, int NST>
-int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s, int terms) {
-  return terms == 1 ? launch_f16x2_t<BM, BN, WM, WN, NST, 1>(p, s) : launch_f16x2_t<BM, BN, WM, WN, NST, 3>(p, s);
+int launch_f16x2(const mfc2::ConvP2& p, hipStream_t s, int terms, int mode = 0) {
+  return terms == 1 ? launch_f16x2_t<BM, BN, WM, WN, NST, 1>(p, s, mode) : launch_f16x2_t<BM, BN, WM, WN, NST, 3>(p, s, mode);
 }
 template <int BM, int BN, int WM, int WN, int HG, int TERMS>
-int launch_halo_t(const mfc2::ConvP2& p, hipStream_t s) {
+int launch_halo_t(const mfc2::ConvP2& p, hipStream_t s, int mode) {
   constexpr size_t lds = (size_t)2 * HG * (WM * WN) * 1024 + (size_t)3 * BN * 128;
   static DeviceOnce once;
-  if (first_use_on_device(once))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mfc2::conv_halo_kernel<BM, BN, WM, WN, HG, TERMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const void* fn = reinterpret_cast<const void*>(&mfc2::conv_halo_kernel<BM, BN, WM, WN, HG, TERMS>);
+  if (first_use_on_device(once)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (mode == 1) return resident_workgroups(fn, WM * WN * 64, lds);
   const int grid = p.tiles_m * p.tiles_n * p.splitk;
   MF_LAUNCH((mfc2::conv_halo_kernel<BM, BN, WM, WN, HG, TERMS>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
   return check_launch("conv_halo");
 }
 template <int BM, int BN, int WM, int WN, int HG>
-int launch_halo(const mfc2::ConvP2& p, hipStream_t s, int terms) {
-  return terms == 1 ? launch_halo_t<BM, BN, WM, WN, HG, 1>(p, s) : launch_halo_t<BM, BN, WM, WN, HG, 3>(p, s);
+int launch_halo(const mfc2::ConvP2& p, hipStream_t s, int terms, int mode = 0) {
+  return terms == 1 ? launch_halo_t<BM, BN, WM, WN, HG, 1>(p, s, mode) : launch_halo_t<BM, BN, WM, WN, HG, 3>(p, s, mode);
+}
+// launch (mode 0) or residency query (mode 1) of tile `id`; -1: no such tile
+int dispatch_tile(int id, const mfc2::ConvP2& p, hipStream_t s, int terms, int mode) {
+  switch (id) {
+    case 31: return launch_f16x2<128, 256, 2, 4, 3>(p, s, terms, mode);
+    case 32: return launch_f16x2<256, 128, 4, 2, 3>(p, s, terms, mode);
+    case 33: return launch_f16x2<128, 128, 2, 4, 3>(p, s, terms, mode);
+    case 34: return launch_f16x2<128, 128, 4, 2, 3>(p, s, terms, mode);
+    case 35: return launch_f16x2<256, 64, 4, 2, 3>(p, s, terms, mode);
+    case 36: return launch_f16x2<128, 64, 4, 2, 3>(p, s, terms, mode);
+    case 37: return launch_f16x2<64, 256, 1, 8, 3>(p, s, terms, mode);
+    case 51: return launch_f16x2<128, 128, 2, 2, 2>(p, s, terms, mode);
+    case 52: return launch_f16x2<128, 128, 2, 2, 3>(p, s, terms, mode);
+    case 53: return launch_f16x2<64, 128, 2, 2, 3>(p, s, terms, mode);
+    case 54: return launch_f16x2<128, 64, 2, 2, 3>(p, s, terms, mode);
+    case 61: return launch_halo<256, 128, 4, 2, 6>(p, s, terms, mode);
+    case 62: return launch_halo<256, 128, 4, 2, 7>(p, s, terms, mode);
+    case 63: return launch_halo<128, 128, 2, 4, 4>(p, s, terms, mode);
+    case 64: return launch_halo<128, 128, 2, 4, 5>(p, s, terms, mode);
+    default: return -1;
+  }
 }
 
 // split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
@@ -319,15 +354,62 @@ int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {
   return cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * (pl.splitk - 1);
 }
 
+// can this convolution apply the GroupNorm that follows it inside its own launch (conv_f16x2.h: FuseP): statistics from the epilogue of
+// the workgroup that holds a tile's final values (no reducer pass), a tile that tells samples apart, and EVERY workgroup of the launch
+// resident at once.  MEDFUSION_FUSED_APPLY=0 switches the form off (A/B).  -> tiles a sample's counter waits for, 0: no
+static int fuse_tiles_per_sample(const MfConvDesc* d, const Plan2& pl, int G) {
+  static const int env = [] { const char* e = getenv("MEDFUSION_FUSED_APPLY"); return e ? atoi(e) : 1; }();
+  if (!env || !pl.ok || G <= 0 || G > 256 || d->Cout % G || d->upsample != 0) return 0;
+  if (pl.splitk > 1 && !tree_possible(d, pl)) return 0;
+  if (!epilogue_stats_ok(d, pl, G)) return 0;
+  const int HW = pl.Hout * pl.Wout;
+  if (HW < pl.t.BM && pl.t.BM / HW > 8) return 0;                          // (at most 8 whole samples per tile: the tail's LDS scratch)
+  const long grid = (long)cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * pl.splitk;
+  mfc2::ConvP2 dummy{};
+  const int resident = dispatch_tile(pl.t.id, dummy, nullptr, d->precision == MF_CONV_F16 ? 1 : 3, 1);
+  if (resident <= 0 || grid > resident) return 0;
+  return (HW >= pl.t.BM ? HW / pl.t.BM : 1) * (d->Cout / pl.t.BN);
+}
+
+int mf_conv2d_f16x2_fuse_words(const MfConvDesc* d, int G) {
+  Plan2 pl;
+  if (!d || !pair_precision(d->precision) || make_plan2(d, &pl) != MF_OK || !pl.ok) return 0;
+  return fuse_tiles_per_sample(d, pl, G) > 0 ? 2 * d->N : 0;
+}
+
+static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
+                           float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                           const MfGnFuse* fz, const MfConvDesc* d, void* stream);
+
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                     float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
                     const MfConvDesc* d, void* stream) {
+  MF_REQUIRE(y, MF_EINVAL, "conv(f16x2): null pointer");
+  return conv_f16x2_impl(x1s, x2s, ws, bias, y, x1_bound, x2_bound, w_bound, y_bound, workspace, workspace_bytes, sync, gn_partial, G, nullptr, d, stream);
+}
+
+int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, const float* bias, const float* x1_bound, const float* x2_bound,
+                             float w_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G, const MfGnFuse* f,
+                             const MfConvDesc* d, void* stream) {
+  MF_REQUIRE(f && gn_partial && G > 0, MF_EINVAL, "conv_gn_apply: needs the fuse arguments, the record array and G");
+  MF_REQUIRE(f->out_split && f->out_bound && f->rendezvous && f->error_flag, MF_EINVAL, "conv_gn_apply: out_split, out_bound, rendezvous and error_flag are required");
+  MF_REQUIRE((f->gamma == nullptr) == (f->beta == nullptr), MF_EINVAL, "conv_gn_apply: gamma/beta must both be given or both NULL");
+  MF_REQUIRE(!(f->residual && f->residual_pairs), MF_EINVAL, "conv_gn_apply: the residual is fp32 OR fp16 pairs");
+  MF_REQUIRE(!f->residual_pairs || f->res_bound, MF_EINVAL, "conv_gn_apply: a residual given as fp16 pairs needs the res_bound that scaled it");
+  MF_REQUIRE(!f->residual || f->res_bound || (f->res_bound_slots && f->res_nslots > 0), MF_EINVAL, "conv_gn_apply: a residual needs res_bound or res_bound_slots");
+  MF_REQUIRE(!f->emb || (f->emb_bound && f->emb_stride % 4 == 0), MF_EINVAL, "conv_gn_apply: an embedding needs emb_bound and emb_stride %% 4 == 0");
+  return conv_f16x2_impl(x1s, x2s, ws, bias, nullptr, x1_bound, x2_bound, w_bound, nullptr, workspace, workspace_bytes, sync, gn_partial, G, f, d, stream);
+}
+
+static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
+                           float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                           const MfGnFuse* fz, const MfConvDesc* d, void* stream) {
   MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2 (or the opt-in MF_CONV_F16)");
   Plan2 pl;
   int rc = make_plan2(d, &pl);
   if (rc) return rc;
   MF_REQUIRE(pl.ok, MF_EUNSUPPORTED, "conv(f16x2): this shape/layout is not on the fp16-pair path (ask mf_conv2d_f16x2_ok)");
-  MF_REQUIRE(x1s && ws && y, MF_EINVAL, "conv(f16x2): null pointer");
+  MF_REQUIRE(x1s && ws && (y || fz), MF_EINVAL, "conv(f16x2): null pointer");
   MF_REQUIRE(d->C2 == 0 || x2s != nullptr, MF_EINVAL, "conv(f16x2): C2 > 0 but x2 is null");
   MF_REQUIRE(!gn_partial || gn_parts2(d, pl, G) > 0, MF_EUNSUPPORTED, "conv(f16x2): cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
   MF_REQUIRE(!y_bound || (!gn_partial && bound_slots2(d, pl, false) > 0), MF_EUNSUPPORTED,
@@ -353,6 +435,16 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
 #if MFC2_HZ & (256 | 512)
   p.dbg = g_conv_dbg;
 #endif
+  memset(&p.fz, 0, sizeof(p.fz));
+  if (fz) {
+    const int tps = fuse_tiles_per_sample(d, pl, G);
+    MF_REQUIRE(tps > 0, MF_EUNSUPPORTED, "conv_gn_apply: this plan cannot apply its GroupNorm inside the launch (mf_conv2d_f16x2_fuse_words == 0)");
+    p.fz.on = 1; p.fz.act = fz->act; p.fz.eps = fz->eps; p.fz.bconst = fz->bconst; p.fz.count = (double)(pl.Hout * pl.Wout) * (d->Cout / G);
+    p.fz.gamma = fz->gamma; p.fz.beta = fz->beta; p.fz.res_f32 = fz->residual; p.fz.res_pairs = fz->residual_pairs;
+    p.fz.res_bound = fz->res_bound; p.fz.res_slots = fz->res_bound ? nullptr : fz->res_bound_slots; p.fz.res_nslots = fz->res_nslots;
+    p.fz.tiles_per_sample = tps; p.fz.emb = fz->emb; p.fz.emb_stride = (long)fz->emb_stride; p.fz.emb_bound = fz->emb_bound;
+    p.fz.out_f32 = fz->out; p.fz.out_pairs = fz->out_split; p.fz.out_bound = fz->out_bound; p.fz.rv = fz->rendezvous; p.fz.rv_err = fz->error_flag;
+  }
   const bool tree = pl.splitk > 1 && tree_possible(d, pl) && (!gn_partial || epilogue_stats_ok(d, pl, G));
   if ((pl.splitk == 1 || tree) && gn_partial) { p.gn_partial = gn_partial; p.gn_parts = p.HWout >= pl.t.BM ? p.HWout / pl.t.BM : 1; }
   if (tree) {
@@ -372,25 +464,9 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
   const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
   {
     const int terms = d->precision == MF_CONV_F16 ? 1 : 3;
-    ProfScope ps(MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
-    switch (pl.t.id) {
-      case 31: rc = launch_f16x2<128, 256, 2, 4, 3>(p, s, terms); break;
-      case 32: rc = launch_f16x2<256, 128, 4, 2, 3>(p, s, terms); break;
-      case 33: rc = launch_f16x2<128, 128, 2, 4, 3>(p, s, terms); break;
-      case 34: rc = launch_f16x2<128, 128, 4, 2, 3>(p, s, terms); break;
-      case 35: rc = launch_f16x2<256, 64, 4, 2, 3>(p, s, terms); break;
-      case 36: rc = launch_f16x2<128, 64, 4, 2, 3>(p, s, terms); break;
-      case 37: rc = launch_f16x2<64, 256, 1, 8, 3>(p, s, terms); break;
-      case 51: rc = launch_f16x2<128, 128, 2, 2, 2>(p, s, terms); break;
-      case 52: rc = launch_f16x2<128, 128, 2, 2, 3>(p, s, terms); break;
-      case 53: rc = launch_f16x2<64, 128, 2, 2, 3>(p, s, terms); break;
-      case 54: rc = launch_f16x2<128, 64, 2, 2, 3>(p, s, terms); break;
-      case 61: rc = launch_halo<256, 128, 4, 2, 6>(p, s, terms); break;
-      case 62: rc = launch_halo<256, 128, 4, 2, 7>(p, s, terms); break;
-      case 63: rc = launch_halo<128, 128, 2, 4, 4>(p, s, terms); break;
-      case 64: rc = launch_halo<128, 128, 2, 4, 5>(p, s, terms); break;
-      default: set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL;
-    }
+    ProfScope ps(fz ? MF_FAM_CONV_GN_FUSED : MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
+    rc = dispatch_tile(pl.t.id, p, s, terms, 0);
+    if (rc == -1) { set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL; }
   }
   if (rc) return rc;
   if (pl.splitk > 1 && !tree) {

@@ -6,6 +6,7 @@ launches on torch's current stream and raises if a tensor is not on the GPU -- t
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -93,6 +94,76 @@ class SyncWords:
         buf = cls._bufs.get((device.index, stream(device.index)))
         if buf is not None and not torch.cuda.is_current_stream_capturing():
             buf.zero_()
+
+
+class Rendezvous:
+    """Counters of the convolutions that apply their GroupNorm inside their own launch (mf_conv2d_f16x2_gn_apply): word 0 is the ERROR FLAG
+    (a wait that did not complete: another process's waiting workgroups filled the device), the [N][2] arrive / depart counters start at
+    word 4.  One array per (device, stream); zero before the first launch, left zero by every launch.  `failed(device)` reads the flags of
+    the device (a host sync): DiffusionPipeline checks once per sampling loop, VAE once per pass, and on a hit zero everything, switch the
+    fused form off for the process (`disabled`) and re-run on the two-launch form."""
+
+    _bufs = {}
+    disabled = os.environ.get("MEDFUSION_FUSED_APPLY", "1") == "0"
+    used = {}          # device index -> a fused launch went out since the last check
+
+    @classmethod
+    def get(cls, words: int, device) -> torch.Tensor:
+        key = (device.index, stream(device.index))
+        buf = cls._bufs.get(key)
+        if buf is None or buf.numel() < words + 4:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("medfusion_amd: rendezvous-counter growth during graph capture; run one eager warm-up first")
+            buf = torch.zeros(max(words + 4, 1 << 12), dtype=torch.int32, device=device)
+            cls._bufs[key] = buf
+            global _growths
+            _growths += 1
+        cls.used[device.index] = True
+        return buf
+
+    @classmethod
+    def failed(cls, device) -> bool:
+        """did a rendezvous of this device time out since the last check?  (host sync; clears flag and counters on a hit)"""
+        if not cls.used.get(device.index):
+            return False
+        cls.used[device.index] = False
+        bad = False
+        for (di, _), buf in cls._bufs.items():
+            if di == device.index and int(buf[0].item()) != 0:
+                bad = True
+        if bad:
+            torch.cuda.synchronize(device)
+            for (di, _), buf in cls._bufs.items():
+                if di == device.index:
+                    buf.zero_()
+        return bad
+
+
+_fused_depth = [0]
+
+
+def with_fused_fallback(device, fn, rewind=None):
+    """Run fn() -- a whole sampling loop, a VAE pass -- and, if one of the convolutions that apply their GroupNorm inside their own launch
+    timed out waiting for its sample (Rendezvous: only when another process's waiting workgroups fill the device), switch that form off for
+    the process, call `rewind()` (restore whatever fn consumed: noise counters) and run fn() again on the two-launch form.  Nested calls
+    (the decode inside a sampling loop) leave the check to the outermost one: a failure anywhere invalidates everything after it."""
+    if _fused_depth[0] > 0 or Rendezvous.disabled or torch.cuda.is_current_stream_capturing():
+        return fn()
+    _fused_depth[0] += 1
+    try:
+        out = fn()
+    finally:
+        _fused_depth[0] -= 1
+    if Rendezvous.failed(device):
+        import warnings
+        Rendezvous.disabled = True
+        warnings.warn("medfusion_amd: a convolution's in-launch GroupNorm rendezvous timed out (the device is shared with another process whose "
+                      "workgroups were waiting too); the fused form is switched off for this process and the pass is re-run on the two-launch form")
+        if rewind is not None:
+            rewind()
+        SyncWords.reset(device)
+        out = fn()
+    return out
 
 
 def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
@@ -323,6 +394,62 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
         out._mf_slots = yb   # GroupNorm-apply pass that takes this tensor as its residual (without slots a consumer measures on demand)
         _stamp(out)
     return (out, partial) if gn_groups else out
+
+
+def conv_fuse_words(d: L.MfConvDesc, G: int) -> int:
+    """rendezvous words mf_conv2d_f16x2_gn_apply needs for `d` followed by a G-group GroupNorm; 0: this convolution cannot apply it itself"""
+    if Rendezvous.disabled:
+        return 0
+    return L.load().mf_conv2d_f16x2_fuse_words(C.byref(d), G)
+
+
+def conv2d_f16x2_gn_apply(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, gamma, beta, G: int, eps: float, parts: int,
+                          words: int, act: int = 1, residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
+                          x2: Optional[torch.Tensor] = None, bconst: float = 0.0, out_fp32: bool = True, pinned=None) -> torch.Tensor:
+    """conv -> GroupNorm -> Swish -> (+ residual) -> (+ emb) in ONE launch (mf_conv2d_f16x2_gn_apply): what conv2d_f16x2(gn_groups=G) followed
+    by gn_apply(GnPartials, split=True) computes, bit for bit.  words = conv_fuse_words(d, G) > 0, parts = conv_gn_parts(d, G) > 0.
+    Returns the result with its fp16-pair mirror and bound attached (out_fp32=False: pairs only, like gn_apply)."""
+    wh, wmax = w_split
+    _gpu(x1, x2, wh, bias, gamma, beta, residual, emb)
+    lib = L.load()
+    x1s, b1 = split_of(x1), bound_of(x1)
+    x2s, b2 = (split_of(x2), bound_of(x2)) if x2 is not None else (None, None)
+    ho, wo = conv_out_hw(d)
+    n, c = d.N, d.Cout
+    dev = x1.device
+    res_pairs = rb = rslots = eb = None
+    if residual is not None:
+        if pairs_only(residual):
+            res_pairs, rb = residual._mf_split, residual._mf_bound
+        elif _fresh(residual, "_mf_bound") is None and _fresh(residual, "_mf_slots") is not None:
+            rslots = residual._mf_slots
+        else:
+            rb = bound_of(residual)
+    if emb is not None:
+        eb = _fresh(emb, "_mf_bound")
+        if eb is None:
+            eb = maxabs_rows(emb.contiguous())
+    out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=dev)
+    outs = torch.empty((n, ho, wo, c), dtype=torch.int32, device=dev)
+    ob = torch.empty((n,), dtype=torch.float32, device=dev)
+    partial = torch.empty((n, parts, G, 2), dtype=torch.float64, device=dev)
+    if pinned is None:
+        pinned = (lib.mf_conv2d_workspace_bytes(C.byref(d)), 0, lib.mf_conv2d_f16x2_sync_words(C.byref(d)))
+    need, _, swords = pinned
+    ws = Workspace.get(need, dev) if need else None
+    sync = SyncWords.get(swords, dev) if swords else None
+    rv = Rendezvous.get(words, dev)
+    f = L.MfGnFuse(_ptr(gamma), _ptr(beta), None if res_pairs is not None else _ptr(residual), _ptr(res_pairs), _ptr(rb), _ptr(rslots), _ptr(emb), _ptr(eb),
+                   out.data_ptr() if out_fp32 else None, outs.data_ptr(), ob.data_ptr(), rv.data_ptr() + 16, rv.data_ptr(), int(emb_stride),
+                   0 if rslots is None else rslots.shape[1], int(act), float(bconst), float(eps))
+    rc = lib.mf_conv2d_f16x2_gn_apply(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), b1.data_ptr(), _ptr(b2), wmax, _ptr(ws), need, _ptr(sync),
+                                      partial.data_ptr(), G, C.byref(f), C.byref(d), stream())
+    L.check(rc, "mf_conv2d_f16x2_gn_apply")
+    out._mf_split, out._mf_bound = outs, ob
+    _stamp(out)
+    if not out_fp32:
+        out._mf_pairs_only = True
+    return out
 
 
 def make_conv_desc(N, Hin, Win, C1, C2, Cout, k, stride, pad, upsample=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC,

@@ -34,8 +34,14 @@ class MfSchedArgs(C.Structure):
                 ("guidance_scale", C.c_float), ("n", C.c_int64)]
 
 
+class MfGnFuse(C.Structure):
+    _fields_ = [("gamma", c_fp), ("beta", c_fp), ("residual", c_fp), ("residual_pairs", c_fp), ("res_bound", c_fp), ("res_bound_slots", c_fp),
+                ("emb", c_fp), ("emb_bound", c_fp), ("out", c_fp), ("out_split", c_fp), ("out_bound", c_fp), ("rendezvous", c_fp), ("error_flag", c_fp),
+                ("emb_stride", C.c_int64), ("res_nslots", C.c_int32), ("act", C.c_int32), ("bconst", C.c_float), ("eps", C.c_float)]
+
+
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
-FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc")
+FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc", "conv_gn_fused")
 
 _I, _I64, _F, _SZ, _U64 = C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 _SIGS = {
@@ -53,6 +59,8 @@ _SIGS = {
     "mf_split_f16x2_slots": (_I, [c_fp, c_fp, c_fp, _I, c_fp, _I, _I64, c_fp]),
     "mf_conv2d_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_sync_words": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_f16x2_fuse_words": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_conv2d_f16x2_gn_apply": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfGnFuse), C.POINTER(MfConvDesc), c_fp]),
     "mf_maxabs_rows_slots": (_I, [_I64]),
     "mf_maxabs_rows_f32": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
     "mf_bound_finalize_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),

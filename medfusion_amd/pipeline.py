@@ -196,7 +196,21 @@ class DiffusionPipeline(nn.Module):
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
         with torch.cuda.device(x_t.device):   # (see sample())
-            return self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **kwargs)
+            from .noise import PhiloxDeviceNoise
+            draws0 = None if noise is None else noise.draw_index
+            trace0 = None if trace is None else len(trace)
+
+            def rewind():   # (a rendezvous of a fused conv + GroupNorm launch timed out: K.with_fused_fallback re-runs the loop un-fused)
+                if trace is not None:
+                    del trace[trace0:]
+                if noise is None:
+                    return
+                if not isinstance(noise, PhiloxDeviceNoise):
+                    raise RuntimeError("medfusion_amd: the sampling loop must be re-run on the two-launch GroupNorm form, but its host noise source "
+                                       "cannot be rewound: set MEDFUSION_FUSED_APPLY=0 when several processes share one GPU")
+                noise.draw_index = draws0
+
+            return K.with_fused_fallback(x_t.device, lambda: self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **dict(kwargs)), rewind)
 
     def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **kwargs):
         K.SyncWords.reset(x_t.device)   # (the split-K counters of the convolutions: zero by invariant, re-zeroed once per loop for robustness)

@@ -29,6 +29,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.MfConvDesc) == 16 * 4
     assert C.sizeof(L.MfSchedStep) == 12 * 4
     assert C.sizeof(L.MfSchedArgs) == 8 * 6 + 8 + 8 * 5 + 4 * 4 + 8  # 6 ptr, i64, 5 ptr, 3 i32 + f32, i64
+    assert C.sizeof(L.MfGnFuse) == 8 * 13 + 8 + 4 * 4                   # 13 ptr, i64, 2 i32 + 2 f32
 
 
 def test_host_validation_without_gpu():
