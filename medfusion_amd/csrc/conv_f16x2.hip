@@ -368,7 +368,10 @@ static int fuse_tiles_per_sample(const MfConvDesc* d, const Plan2& pl, int G) {
   mfc2::ConvP2 dummy{};
   const int resident = dispatch_tile(pl.t.id, dummy, nullptr, d->precision == MF_CONV_F16 ? 1 : 3, 1);
   if (resident <= 0 || grid > resident) return 0;
-  return (HW >= pl.t.BM ? HW / pl.t.BM : 1) * (d->Cout / pl.t.BN);
+  // MEDFUSION_FUSE_FAULT=1 (tests only): one arrival too many is awaited, so every rendezvous times out -- exercises the error flag and the
+  // host's re-run on the two-launch form
+  static const int fault = [] { const char* e = getenv("MEDFUSION_FUSE_FAULT"); return e ? atoi(e) : 0; }();
+  return (HW >= pl.t.BM ? HW / pl.t.BM : 1) * (d->Cout / pl.t.BN) + (fault ? 1 : 0);
 }
 
 int mf_conv2d_f16x2_fuse_words(const MfConvDesc* d, int G) {

@@ -928,6 +928,170 @@ def test_gn_apply_pairs_only_output_and_residual_from_pairs(dev):
     assert torch.equal(o_po._mf_bound, o_full._mf_bound)
 
 
+FUSED_CASES = [
+    # (N, H, W, C1, C2, Cout, k, G, tile, split-K, residual, emb, out_fp32)   residual: none | f32 (identity, bound known) | pairs (pairs-only) | slots (a conv_res output)
+    (16, 32, 32, 256, 0, 256, 3, 32, 52, 1, "f32", True, True),       # the dominant launch of cfg2: 256 workgroups, 16 tiles per sample
+    (16, 32, 32, 256, 0, 256, 3, 32, 52, 1, "pairs", False, False),   # ... as the second convolution of a ResBlock (residual and output as pairs only)
+    (16, 16, 16, 512, 0, 512, 3, 32, 52, 2, "pairs", True, False),    # in-launch split-K in front of the rendezvous
+    (16, 16, 16, 256, 0, 512, 3, 32, 36, 1, "slots", True, True),     # 8-wave 128 x 64 tile, residual bound from the slots of a 1x1 conv_res
+    (16, 8, 8, 1024, 0, 1024, 3, 32, 52, 4, "f32", True, True),       # TWO samples per tile (HW = 64 < BM = 128), two tree levels
+    (16, 8, 8, 1024, 1024, 1024, 3, 32, 51, 8, "slots", False, True), # two-source concat, 512 workgroups two per CU
+    (16, 8, 8, 512, 0, 1024, 3, 32, 53, 2, "none", True, True),       # 64-row tile: one sample per tile at 8 x 8
+    (16, 32, 32, 256, 256, 256, 3, 32, 62, 2, "slots", True, False),  # halo tile (256 rows), two-source
+    (16, 32, 32, 512, 0, 256, 3, 32, 0, 0, "f32", False, True),       # the planner's own choice
+    (2, 8, 8, 64, 32, 128, 3, 8, 0, 0, "f32", True, True),            # a tiny launch (two workgroups), G = 8
+    (3, 16, 16, 64, 0, 128, 1, 8, 0, 0, "none", False, True),         # 1x1, N = 3
+    (5, 8, 8, 96, 32, 256, 3, 32, 32, 1, "f32", True, True),          # 256-row tile holding FOUR 8 x 8 samples, the last tile ragged (N = 5)
+]
+
+
+def _fused_operands(case, dev):
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, G, tile, sk, rkind, use_emb, out_fp32 = case
+    x = K.nchw_to_nhwc((_rand(f"fx{case}", (n, c1, h, w)) * torch.tensor([[1.0, 300.0, 1e-3, 7.0][i % 4] for i in range(n)]).view(n, 1, 1, 1)).to(dev))
+    x2 = K.nchw_to_nhwc(_rand(f"fy{case}", (n, c2, h, w)).to(dev)) if c2 else None
+    wh = K.split_weight_f16x2(K.pack_conv_weight(_rand(f"fw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k)).to(dev)))
+    b = _rand(f"fb{case}", (co,), 0.1).to(dev)
+    gamma, beta = (1 + 0.2 * _rand(f"fg{case}", (co,))).to(dev), _rand(f"fz{case}", (co,), 0.1).to(dev)
+    emb = _rand(f"fe{case}", (n, co)).to(dev) if use_emb else None
+    pad = R.monai_padding(k, 1)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, 1, pad, 0, tile_hint=tile, splitk_hint=sk, precision=5)
+
+    def residual():
+        if rkind == "none":
+            return None
+        if rkind == "slots":   # the output of a 1x1 conv_res that measured its own bound: fp32 values + per-(tile, wave) slot maxima
+            w1 = K.split_weight_f16x2(K.pack_conv_weight(_rand(f"fr{case}", (co, c1 + c2, 1, 1), 1.0 / np.sqrt(c1 + c2)).to(dev)))
+            d1 = K.make_conv_desc(n, h, w, c1, c2, co, 1, 1, 0, 0, precision=5)
+            r = K.conv2d_f16x2(x, w1, b, d1, x2=x2, measure_out=True)
+            assert getattr(r, "_mf_slots", None) is not None
+            return r
+        r = K.nchw_to_nhwc((2.0 * _rand(f"fq{case}", (n, co, h, w))).to(dev))
+        if rkind == "pairs":   # exists as fp16 pairs only (the output of the previous apply pass of a ResBlock)
+            K.split_of(r)
+            r._mf_pairs_only = True
+        return r
+
+    bc = float(gamma.abs().max()) * (h * w * co // G) ** 0.5 + float(beta.abs().max())
+    return x, x2, wh, b, gamma, beta, emb, d, residual, bc
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_gn_apply_in_one_launch_equals_the_two_launch_form(dev, case):
+    """mf_conv2d_f16x2_gn_apply (round 4: the GroupNorm + Swish + residual + embedding pass inside the convolution's launch, the tiles of a
+    sample meeting at a counter) against mf_conv2d_f16x2 + mf_gn_apply_from_partials_pairs_f32 on the same operands: the fp16-pair output,
+    its bound and -- where written -- the fp32 output must be IDENTICAL (same records, same summation order, same per-element operations);
+    300 further launches alternating between two inputs check that every launch leaves its counters zero and that nothing races."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, G, tile, sk, rkind, use_emb, out_fp32 = case
+    x, x2, wh, b, gamma, beta, emb, d, residual, bc = _fused_operands(case, dev)
+    parts, words = K.conv_gn_parts(d, G), K.conv_fuse_words(d, G)
+    if tile == 0 and (parts == 0 or words == 0):
+        pytest.skip("the planner's own plan for this shape has no fused form")
+    assert parts > 0 and words == 2 * n, (case, parts, words)
+
+    def two_launches(xin):
+        res = residual()
+        y, partial = K.conv2d_f16x2(xin, wh, b, d, x2=x2, gn_groups=G, gn_parts=parts)
+        return K.gn_apply(y, K.GnPartials(partial, parts, 1e-5), gamma, beta, G, 1, res, emb, emb.stride(0) if emb is not None else 0, out=y, split=True,
+                          bconst=bc, out_fp32=out_fp32)
+
+    def one_launch(xin):
+        return K.conv2d_f16x2_gn_apply(xin, wh, b, d, gamma, beta, G, 1e-5, parts, words, act=1, residual=residual(), emb=emb,
+                                       emb_stride=emb.stride(0) if emb is not None else 0, x2=x2, bconst=bc, out_fp32=out_fp32)
+
+    xb = x * 1.5 + 0.25
+    K.split_of(xb)
+    refs = [two_launches(x), two_launches(xb)]
+    for it in range(302):
+        which = it & 1
+        got = one_launch(xb if which else x)
+        if it < 2 or it % 50 == 0 or it == 301:
+            ref = refs[which]
+            assert K.pairs_only(got) == (not out_fp32)
+            assert torch.equal(got._mf_bound, ref._mf_bound), (case, it)
+            assert torch.equal(got._mf_split, ref._mf_split), (case, it, int((got._mf_split != ref._mf_split).sum()))
+            if out_fp32:
+                assert torch.equal(got, ref), (case, it)
+    rv = K.Rendezvous.get(words, dev)
+    torch.cuda.synchronize()
+    assert int(rv.abs().sum().item()) == 0, "a launch left its rendezvous counters (or the error flag) non-zero"
+    # against an fp64 evaluation of GroupNorm, Swish, residual, embedding on the convolution's fp32 output (the convolution itself is
+    # checked in test_conv_f16x2); pair tensors decoded on the host: (hi + lo / 2048) 2^s
+    def decoded(t):
+        return (_decode_pairs(t._mf_split, t.shape) * torch.exp2(_scale_exp(t._mf_bound)).double().view(-1, 1, 1, 1)).permute(0, 3, 1, 2)
+
+    res = residual()
+    resv = None if res is None else (decoded(res) if rkind == "pairs" else K.nhwc_to_nchw(res).cpu().double())
+    got = one_launch(x)
+    y64 = K.nhwc_to_nchw(K.conv2d_f16x2(x, wh, b, d, x2=x2)).cpu().double()
+    yn = F.group_norm(y64, G, gamma.cpu().double(), beta.cpu().double(), 1e-5)
+    want = yn * torch.sigmoid(yn)
+    if resv is not None:
+        want = want + resv
+    if emb is not None:
+        want = want + emb.cpu().double().view(n, co, 1, 1)
+    assert relerr(decoded(got), want) < 2e-6, case
+
+
+def _scale_exp(bound):
+    """the exponent s of the per-sample scale 2^s (csrc/split_f16.h: floor(log2 bound) - 14)"""
+    return (torch.floor(torch.log2(bound.double())) - 14).clamp(-100, 100).float().cpu()
+
+
+def test_conv_gn_apply_fused_refuses_what_it_cannot_do(dev):
+    """plans whose workgroups are not all resident at once (or that reduce split-K through a reducer pass) have no fused form:
+    mf_conv2d_f16x2_fuse_words says 0 and the entry point refuses"""
+    from medfusion_amd import kernels as K
+    big = K.make_conv_desc(16, 128, 128, 128, 0, 128, 3, 1, 1, 0, precision=5)          # VAE 128^2 level: thousands of workgroups
+    assert K.conv_f16x2_ok(big) and K.conv_fuse_words(big, 32) == 0
+    odd = K.make_conv_desc(16, 16, 16, 384, 0, 512, 3, 1, 1, 0, tile_hint=52, splitk_hint=3, precision=5)   # split-K 3: slabs + reducer pass
+    assert K.conv_f16x2_ok(odd) and K.conv_fuse_words(odd, 32) == 0
+    ok = K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5)
+    assert K.conv_fuse_words(ok, 32) == 32
+
+
+FAULT = r"""
+import os, sys, warnings, torch
+sys.path.insert(0, {root!r})
+import medfusion_amd as M
+from medfusion_amd import kernels as K, published as P
+from medfusion_amd.unet import UNet, TimeEmbbeding
+dev = torch.device("cuda:0")
+ukw = dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[64, 64, 128, 128], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], time_embedder=TimeEmbbeding,
+           time_embedder_kwargs={{"emb_dim": 64}}, cond_embedder=None, deep_supervision=False, use_res_block=True, use_attention="none")
+pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, UNet, None, P.published_scheduler_kwargs(), ukw, estimator_objective="x_T", clip_x0=False)
+P.seeded_fill(pipe.noise_estimator, "fault.unet.")
+pipe.to(dev).eval()
+assert not K.Rendezvous.disabled
+with warnings.catch_warnings(record=True) as wl:
+    warnings.simplefilter("always")
+    a = pipe.sample(2, (8, 16, 16), noise=M.PhiloxDeviceNoise(9), steps=6, use_ddim=True)
+torch.cuda.synchronize()
+print("FAULT_MODE", os.environ.get("MEDFUSION_FUSE_FAULT"), "disabled after:", K.Rendezvous.disabled, "warnings:", len([w for w in wl if "rendezvous" in str(w.message)]))
+torch.save(a.cpu(), sys.argv[1])
+"""
+
+
+def test_fused_rendezvous_timeout_falls_back_to_the_two_launch_form(dev, tmp_path):
+    """MEDFUSION_FUSE_FAULT=1 makes every rendezvous wait for one arrival too many: the first fused launch times out (50 ms), raises the error
+    flag, every later one stops waiting; sample() sees the flag at the end of its loop, switches the fused form off, rewinds the noise
+    counter and re-runs -- the images equal those of a process that never fused (MEDFUSION_FUSED_APPLY=0) and of a healthy fused run."""
+    import subprocess
+    script = tmp_path / "fault.py"
+    script.write_text(FAULT.format(root=str(ROOT)))
+    outs = {}
+    for tag, env_extra in (("fault", {"MEDFUSION_FUSE_FAULT": "1"}), ("off", {"MEDFUSION_FUSED_APPLY": "0"}), ("on", {})):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.pt")], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[tag] = (torch.load(tmp_path / f"{tag}.pt"), [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT_MODE")][-1])
+    assert "disabled after: True warnings: 1" in outs["fault"][1], outs["fault"][1]
+    assert "disabled after: False" in outs["on"][1] and "disabled after: True" in outs["off"][1]
+    assert torch.equal(outs["fault"][0], outs["off"][0])
+    assert torch.equal(outs["on"][0], outs["off"][0])       # the fused form IS the two-launch form, bit for bit, through a whole sampling loop
+
+
 @pytest.mark.parametrize("shape", [(16, 32, 32, 256, 256, 256), (16, 16, 16, 512, 512, 512), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512)])
 def test_conv_f16x2_two_source_1x1_at_published_sizes(dev, shape):
     """conv_res of the out-blocks at the cfg2 batch (two-source concat, planner's own tile / split-K incl. the in-launch reduction): exact to
