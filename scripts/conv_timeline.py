@@ -17,6 +17,7 @@ from medfusion_amd import lib as L
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--fused", action="store_true", help="time mf_conv2d_f16x2_gn_apply (GroupNorm + Swish + residual + embedding inside the launch) instead")
     ap.add_argument("--shapes", default="16,32,32,256,0,256,3:52:1;16,16,16,512,0,512,3:52:2;16,8,8,1024,0,1024,3:53:4;16,32,32,512,0,256,1:52:1")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -37,13 +38,26 @@ def main():
         parts = K.conv_gn_parts(d, 32)
         y = torch.empty((n, h, w, co), device=dev)
         setter(None)
+        if args.fused:
+            words = K.conv_fuse_words(d, 32)
+            gamma, beta = torch.rand((co,), device=dev) + 0.5, torch.randn((co,), device=dev) * 0.1
+            res = torch.randn((n, h, w, co), device=dev)
+            K.split_of(res)
+            emb = torch.randn((n, co), device=dev)
+            emb._mf_bound = emb.abs().amax(1)
+            if not words:
+                print(f"{shp} tile {tile} split-K {sk}: no fused form")
+                continue
+            run = lambda: K.conv2d_f16x2_gn_apply(x, wh, b, d, gamma, beta, 32, 1e-5, parts, words, act=1, residual=res, emb=emb, emb_stride=co, bconst=30.0, out_fp32=False)
+        else:
+            run = lambda: K.conv2d_f16x2(x, wh, b, d, out=y, gn_groups=32, gn_parts=parts)
         for _ in range(5):
-            K.conv2d_f16x2(x, wh, b, d, out=y, gn_groups=32, gn_parts=parts)
+            run()
         bufs = [torch.zeros((8192, 8), dtype=torch.int64, device=dev) for _ in range(3)]
         torch.cuda.synchronize()
         for bf in bufs:
             setter(bf.data_ptr())
-            K.conv2d_f16x2(x, wh, b, d, out=y, gn_groups=32, gn_parts=parts)
+            run()
         setter(None)
         torch.cuda.synchronize()
         A, B = (bf[bf[:, 0] > 0].double() * 0.01 for bf in bufs[1:])   # us
@@ -55,7 +69,9 @@ def main():
               f"ramp median {med(B[:, 1] - B[:, 0]):5.2f} max {float((B[:, 1] - B[:, 0]).max()):5.2f} | loop median {med(B[:, 2] - B[:, 1]):6.2f} | "
               f"drain median {med(Bx[:, 3] - Bx[:, 2]):5.2f} max {float((Bx[:, 3] - Bx[:, 2]).max()):5.2f} | tail {float(Bx[:, 3].max()) - med(Bx[:, 3]):5.2f} | "
               f"first entry -> last exit {float(B[:, 3].max() - t0):6.2f} || inside the drain (medians): wait for the other waves {med(Bx[:, 4] - Bx[:, 2]):5.2f}, "
-              f"split-K tree {med(Bx[:, 5] - Bx[:, 4]):5.2f}, staging + stores {med(Bx[:, 6] - Bx[:, 5]):5.2f}, bounds + GroupNorm records {med(Bx[:, 3] - Bx[:, 6]):5.2f}", flush=True)
+              f"split-K tree {med(Bx[:, 5] - Bx[:, 4]):5.2f}, " + (f"staging + records + arrival {med(Bx[:, 6] - Bx[:, 5]):5.2f}, wait for the sample (constants and residual loads issued) "
+              f"median {med(Bx[:, 7] - Bx[:, 6]):5.2f} max {float((Bx[:, 7] - Bx[:, 6]).max()):5.2f} min {float((Bx[:, 7] - Bx[:, 6]).min()):5.2f}, finalize + apply + stores {med(Bx[:, 3] - Bx[:, 7]):5.2f}"
+              if args.fused else f"staging + stores {med(Bx[:, 6] - Bx[:, 5]):5.2f}, bounds + GroupNorm records {med(Bx[:, 3] - Bx[:, 6]):5.2f}"), flush=True)
 
 
 if __name__ == "__main__":
