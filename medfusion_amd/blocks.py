@@ -161,7 +161,8 @@ class Conv(nn.Module):
         if ent is None:
             d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=prec)
             ent = (None, 0, 0, None)
-            if K.conv_f16x2_ok(d) and not self.upsample:
+            ho, wo = K.conv_out_hw(d)
+            if K.conv_f16x2_ok(d) and not self.upsample and ho * wo >= K.FUSE_MIN_HW:
                 pinned = K.pin_conv_plan(d)
                 parts, words = K.conv_gn_parts(d, G), K.conv_fuse_words(d, G)
                 if parts > 0 and words > 0:

@@ -87,14 +87,22 @@ __device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x))
 // accurate variant used where parity margins are tight (embedding MLPs): expf, IEEE divide
 __device__ __forceinline__ float swish_acc(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 #ifndef MF_SWISH_APPLY
-#define MF_SWISH_APPLY 0
+#define MF_SWISH_APPLY 3
 #endif
 // the GroupNorm apply pass's form (VALU-bound pass: 28 of its ~55 instructions per element are this function).  0: swish_acc.
 // 1: the IEEE division (12 instructions) replaced by v_rcp_f32 + one Newton step (4; error < 1 ulp).  2: additionally expf without its
 // overflow / underflow selects (the sigmoid saturates by itself: exp -> inf gives x * 0, exp -> 0 gives x).
+// 3 (default since round 4): x * v_rcp(1 + v_exp(x * -log2 e)) -- five instructions.  Both hardware functions are good to 1 ulp; the rounding of
+// the exponent's argument adds |x| 6e-8 to the relative error of e^-x, which only shows where the sigmoid is small (x << 0, where the
+// result itself is ~0): |error| < 3 ulp of the result, or 1e-8 absolute, whichever is larger -- the fp32 class of the path's 1e-4 tolerance
+// (measured at block and trajectory level: profiles/r04_*).  The apply pass and the fused tail of the convolution are VALU-bound
+// (scripts/conv_timeline.py --fused: 70 instructions per element, 28 of them the IEEE form of this function), hence the short form.
+// x -> -inf gives -inf * 0 = NaN like x * sigmoid(x) of the reference; x -> +inf gives x.
 __device__ __forceinline__ float swish_apply(float x) {
 #if MF_SWISH_APPLY == 0
   return swish_acc(x);
+#elif MF_SWISH_APPLY == 3
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 #else
 #if MF_SWISH_APPLY == 1
   const float d = 1.0f + expf(-x);

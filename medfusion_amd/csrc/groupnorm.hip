@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(const float* __restr
         } else if (res_f) { e[0] += r[u].x; e[1] += r[u].y; e[2] += r[u].z; e[3] += r[u].w; }
         if (emb) { e[0] += kc.em.x; e[1] += kc.em.y; e[2] += kc.em.z; e[3] += kc.em.w; }
         if (!SPLIT || out) *reinterpret_cast<float4*>(out + (base + j) * 4) = make_float4(e[0], e[1], e[2], e[3]);   // (null: pairs only)
-        if (SPLIT) store_split4(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);
+        if (SPLIT) store_split4<false>(sp.outs, (base + j) * 4, e[0], e[1], e[2], e[3], sc);   // (the bound is derived: no clamp, split_f16.h)
       }
     }
     jw += step;

@@ -106,6 +106,7 @@ class Rendezvous:
     _bufs = {}
     disabled = os.environ.get("MEDFUSION_FUSED_APPLY", "1") == "0"
     used = {}          # device index -> a fused launch went out since the last check
+    launches = 0       # fused launches issued by this process (tests, diagnostics)
 
     @classmethod
     def get(cls, words: int, device) -> torch.Tensor:
@@ -119,6 +120,7 @@ class Rendezvous:
             global _growths
             _growths += 1
         cls.used[device.index] = True
+        cls.launches += 1
         return buf
 
     @classmethod
@@ -139,6 +141,10 @@ class Rendezvous:
         return bad
 
 
+# Policy (blocks.py): a convolution applies its GroupNorm itself only from this many output pixels per sample on.  Below, the tiles of a
+# sample finish too far apart (deep in-launch split-K trees at 8 x 8) for the wait to beat a separate apply launch (scripts/conv_timeline.py
+# --fused, profiles/r04_conv_timeline_fused.txt).  The C-ABI query (mf_conv2d_f16x2_fuse_words) answers capability only.
+FUSE_MIN_HW = int(os.environ.get("MEDFUSION_FUSE_MIN_HW", "256"))
 _fused_depth = [0]
 
 

@@ -1069,16 +1069,17 @@ import medfusion_amd as M
 from medfusion_amd import kernels as K, published as P
 from medfusion_amd.unet import UNet, TimeEmbbeding
 dev = torch.device("cuda:0")
-ukw = dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[64, 64, 128, 128], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], time_embedder=TimeEmbbeding,
+ukw = dict(in_ch=8, out_ch=8, spatial_dims=2, hid_chs=[256, 256, 256, 512], kernel_sizes=[3] * 4, strides=[1, 2, 2, 2], time_embedder=TimeEmbbeding,
            time_embedder_kwargs={{"emb_dim": 64}}, cond_embedder=None, deep_supervision=False, use_res_block=True, use_attention="none")
 pipe = M.DiffusionPipeline(M.GaussianNoiseScheduler, UNet, None, P.published_scheduler_kwargs(), ukw, estimator_objective="x_T", clip_x0=False)
-P.seeded_fill(pipe.noise_estimator, "fault.unet.")
+P.seeded_fill(pipe.noise_estimator, "fault.unet.")   # (widths >= 256: 32 groups of >= 8 channels, what the convolution's epilogue can take statistics of)
 pipe.to(dev).eval()
 with warnings.catch_warnings(record=True) as wl:
     warnings.simplefilter("always")
     a = pipe.sample(2, (8, 16, 16), noise=M.PhiloxDeviceNoise(9), steps=6, use_ddim=True)
 torch.cuda.synchronize()
-print("FAULT_MODE", os.environ.get("MEDFUSION_FUSE_FAULT"), "disabled after:", K.Rendezvous.disabled, "warnings:", len([w for w in wl if "rendezvous" in str(w.message)]))
+print("FAULT_MODE", os.environ.get("MEDFUSION_FUSE_FAULT"), "disabled after:", K.Rendezvous.disabled, "warnings:", len([w for w in wl if "rendezvous" in str(w.message)]),
+      "fused launches:", K.Rendezvous.launches)
 torch.save(a.cpu(), sys.argv[1])
 """
 
@@ -1098,6 +1099,7 @@ def test_fused_rendezvous_timeout_falls_back_to_the_two_launch_form(dev, tmp_pat
         outs[tag] = (torch.load(tmp_path / f"{tag}.pt"), [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT_MODE")][-1])
     assert "disabled after: True warnings: 1" in outs["fault"][1], outs["fault"][1]
     assert "disabled after: False" in outs["on"][1] and "disabled after: True" in outs["off"][1]
+    assert int(outs["on"][1].rsplit(":", 1)[1]) > 0 and int(outs["off"][1].rsplit(":", 1)[1]) == 0   # the healthy run did fuse, the switched-off one never
     assert torch.equal(outs["fault"][0], outs["off"][0])
     assert torch.equal(outs["on"][0], outs["off"][0])       # the fused form IS the two-launch form, bit for bit, through a whole sampling loop
 
