@@ -141,7 +141,9 @@ int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk)
  * `error_flag`: one zero-initialised word; a wait that does not complete within 50 ms (another process's waiting workgroups filling the
  * device) sets it, later launches stop waiting, and the results since are INVALID: the caller checks it at the end of its loop, zeroes
  * flag and rendezvous words, and re-runs on the two-launch form.  Arguments as in the two calls it replaces; out may be NULL (fp16 pairs
- * only), out_split / out_bound are required.  MEDFUSION_FUSED_APPLY=0 in the environment (read once) makes fuse_words return 0. */
+ * only), out_split / out_bound are required.  MEASURED (round 4, profiles/r04_fused_gn_apply_ab.txt, r04_conv_timeline_fused.txt): not
+ * faster than the two launches on MI355X -- the tail (records, rendezvous, finalize, apply at one wave per SIMD) costs what the kernel
+ * boundary plus the stand-alone pass cost -- so the Python host keeps it opt-in (MEDFUSION_FUSED_APPLY=1). */
 typedef struct MfGnFuse {
   const float* gamma;            /* [Cout] or NULL (both) */
   const float* beta;

@@ -356,10 +356,10 @@ int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {
 
 // can this convolution apply the GroupNorm that follows it inside its own launch (conv_f16x2.h: FuseP): statistics from the epilogue of
 // the workgroup that holds a tile's final values (no reducer pass), a tile that tells samples apart, and EVERY workgroup of the launch
-// resident at once.  MEDFUSION_FUSED_APPLY=0 switches the form off (A/B).  -> tiles a sample's counter waits for, 0: no
+// resident at once.  -> tiles a sample's counter waits for, 0: no.  (Capability only: whether a caller USES the form is its policy -- the
+// Python host keeps it opt-in, MEDFUSION_FUSED_APPLY=1: measured not faster than the two launches, profiles/r04_fused_gn_apply_ab.txt.)
 static int fuse_tiles_per_sample(const MfConvDesc* d, const Plan2& pl, int G) {
-  static const int env = [] { const char* e = getenv("MEDFUSION_FUSED_APPLY"); return e ? atoi(e) : 1; }();
-  if (!env || !pl.ok || G <= 0 || G > 256 || d->Cout % G || d->upsample != 0) return 0;
+  if (!pl.ok || G <= 0 || G > 256 || d->Cout % G || d->upsample != 0) return 0;
   if (pl.splitk > 1 && !tree_possible(d, pl)) return 0;
   if (!epilogue_stats_ok(d, pl, G)) return 0;
   const int HW = pl.Hout * pl.Wout;

@@ -76,7 +76,12 @@ __device__ __forceinline__ void store_split4(void* ys, long e, float a, float b,
   const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
   const unsigned r1 = (unsigned)__builtin_amdgcn_mov_dpp((int)s1, 0xB1, 0xF, 0xF, true);
   const sf_u32x4 v = odd ? sf_u32x4{r0, r1, l0, l1} : sf_u32x4{h0, h1, r0, r1};
+#if defined(MF_GN_OUT_SC1) && MF_GN_OUT_SC1   /* experiment (round 4): write-through (sc1) stores, see conv_f16x2_epilogue.inc MFC2_OUT_STORE == 2 */
+  sf_u32x4* q_ = reinterpret_cast<sf_u32x4*>(ys) + ((e >> 3) * 2 + (odd ? 1 : 0));
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q_), "v"(v) : "memory");
+#else
   reinterpret_cast<sf_u32x4*>(ys)[(e >> 3) * 2 + (odd ? 1 : 0)] = v;
+#endif
 }
 
 // Measured bounds: thousands of waves updating the same few words with atomics serialise on one L2 channel (measured: 66 us for a 10 us

@@ -104,7 +104,10 @@ class Rendezvous:
     fused form off for the process (`disabled`) and re-run on the two-launch form."""
 
     _bufs = {}
-    disabled = os.environ.get("MEDFUSION_FUSED_APPLY", "1") == "0"
+    # OPT-IN (MEDFUSION_FUSED_APPLY=1): built, bit-identical to the two-launch form, and measured NOT faster -- same-process A/B on cfg2,
+    # profiles/r04_fused_gn_apply_ab.txt: -0.2 % (fused at 32 x 32 only) ... -2.2 % (everywhere); the tail costs what the boundary + the
+    # apply launch cost (profiles/r04_conv_timeline_fused.txt).  So the default is the two-launch form, which also never waits in a kernel.
+    disabled = os.environ.get("MEDFUSION_FUSED_APPLY", "0") != "1"
     used = {}          # device index -> a fused launch went out since the last check
     launches = 0       # fused launches issued by this process (tests, diagnostics)
 
@@ -403,9 +406,8 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
 
 
 def conv_fuse_words(d: L.MfConvDesc, G: int) -> int:
-    """rendezvous words mf_conv2d_f16x2_gn_apply needs for `d` followed by a G-group GroupNorm; 0: this convolution cannot apply it itself"""
-    if Rendezvous.disabled:
-        return 0
+    """rendezvous words mf_conv2d_f16x2_gn_apply needs for `d` followed by a G-group GroupNorm; 0: this convolution cannot apply it itself
+    (capability; whether blocks.py uses the form is Rendezvous.disabled / FUSE_MIN_HW)"""
     return L.load().mf_conv2d_f16x2_fuse_words(C.byref(d), G)
 
 

@@ -1087,12 +1087,13 @@ torch.save(a.cpu(), sys.argv[1])
 def test_fused_rendezvous_timeout_falls_back_to_the_two_launch_form(dev, tmp_path):
     """MEDFUSION_FUSE_FAULT=1 makes every rendezvous wait for one arrival too many: the first fused launch times out (50 ms), raises the error
     flag, every later one stops waiting; sample() sees the flag at the end of its loop, switches the fused form off, rewinds the noise
-    counter and re-runs -- the images equal those of a process that never fused (MEDFUSION_FUSED_APPLY=0) and of a healthy fused run."""
+    counter and re-runs -- the images equal those of a process that never fused (the default) and of a healthy fused run (the opt-in
+    MEDFUSION_FUSED_APPLY=1)."""
     import subprocess
     script = tmp_path / "fault.py"
     script.write_text(FAULT.format(root=str(ROOT)))
     outs = {}
-    for tag, env_extra in (("fault", {"MEDFUSION_FUSE_FAULT": "1"}), ("off", {"MEDFUSION_FUSED_APPLY": "0"}), ("on", {})):
+    for tag, env_extra in (("fault", {"MEDFUSION_FUSE_FAULT": "1", "MEDFUSION_FUSED_APPLY": "1"}), ("off", {"MEDFUSION_FUSED_APPLY": "0"}), ("on", {"MEDFUSION_FUSED_APPLY": "1"})):
         env = dict(os.environ, **env_extra)
         r = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.pt")], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
