@@ -25,7 +25,7 @@ from .noise import NoiseSource, default_noise
 from .scheduler import GaussianNoiseScheduler
 
 
-_CMD_POOLS = {}       # device index -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from (process-wide)
+_CMD_POOLS = {}       # (device index, stream) -> torch.cuda.MemPool the recorded iteration of the command-list loop allocates from (process-wide)
 _GRAPH_STREAMS = {}   # device index -> the one side stream graph captures run on
 
 
@@ -386,9 +386,9 @@ class DiffusionPipeline(nn.Module):
             cur = K.stream(dev.index)
             first_iteration()
             if len(rev) > 1:
-                pool = _CMD_POOLS.get(dev.index)
+                pool = _CMD_POOLS.get((dev.index, cur))    # one pool per (device, stream): two threads driving two streams record independently
                 if pool is None:
-                    pool = _CMD_POOLS[dev.index] = torch.cuda.MemPool()
+                    pool = _CMD_POOLS[(dev.index, cur)] = torch.cuda.MemPool()
                 handle = ctypes.c_void_p()
                 guard = _PureLaunchGuard()
                 grew = K.scratch_growth_count()

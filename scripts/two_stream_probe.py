@@ -5,11 +5,10 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import medfusion_amd as M
-from bench import build_pipeline
+from medfusion_amd import published as P
 
 dev = torch.device("cuda:0")
-pipe = build_pipeline(dev, None)
-pipe.latent_embedder_saved = pipe.latent_embedder
+pipe = P.build_published_pipeline(dev, None)
 STEPS = 40
 
 def run(n, seed, stream, out, idx):
