@@ -169,6 +169,17 @@ int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, c
                              float w_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
                              const MfGnFuse* f, const MfConvDesc* d, void* stream);
 
+/* The same convolution writing its output ALSO as fp16 pairs (ABI 220), for outputs that feed convolutions un-normalised (BasicDown /
+ * BasicUp, conv_blocks.py:66,123-125): the per-sample scale comes from a bound DERIVED from the operands, |y[n]| <= x1_bound[n] w_l1_1 +
+ * x2_bound[n] w_l1_2 + bias_max with w_l1 = max over the output channels of the L1 norm of the filter over that source's channels (host,
+ * once per weight tensor) -- rigorous, a few binades above the true maximum (the pair format keeps its 23 bits down to 2^-28 of the bound),
+ * so no measuring epilogue, no mf_split_f16x2_slots launch behind the convolution.  y_bound_out[N] receives the bound.  Only for plans
+ * whose final values exist inside the launch: mf_conv2d_f16x2_pairs_out_ok(d). */
+int mf_conv2d_f16x2_pairs_out_ok(const MfConvDesc* d);
+int mf_conv2d_f16x2_pairs_out(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* y_split, float* y_bound_out,
+                              const float* x1_bound, const float* x2_bound, float w_bound, float w_l1_1, float w_l1_2, float bias_max,
+                              void* workspace, size_t workspace_bytes, uint32_t* sync, const MfConvDesc* d, void* stream);
+
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
  * parts = mf_conv2d_gn_parts(d, G); 0 means this convolution cannot emit them (use mf_gn_stats_partial_f32). */
@@ -292,12 +303,22 @@ typedef struct MfSchedArgs {
   int64_t n;                 /* elements */
 } MfSchedArgs;
 int mf_sched_step_f32(const MfSchedArgs* a, void* stream);
+/* The tail of a denoise iteration in ONE launch (ABI 220): the posterior draw and the DDIM draw of mf_philox_normal_f32 (draw indices
+ * draw_base + draw_stride * step and + 1, rows sample_offset .. + B) are generated in registers, mf_sched_step_f32's arithmetic runs on
+ * them -- bit for bit what the three launches produce -- and *step_counter (read as the step; a->step_dev / a->step are ignored) is
+ * incremented by the workgroup that finishes last (`ticket`: one zero-initialised word the launch leaves zero).  a->noise_post / noise_ddim
+ * must be NULL.  Replaces torch.randn_like x 2 + the ~49 elementwise ATen ops + the host loop counter of diffusion_pipeline.py:294-304. */
+int mf_sched_step_philox_f32(const MfSchedArgs* a, uint64_t seed, int32_t draw_base, int32_t draw_stride, int64_t sample_offset, int B,
+                             int32_t* step_counter, uint32_t* ticket, void* stream);
 /* out[0..n) = table[step] with step = *step_dev (or `step`): `t.expand(B)` of diffusion_pipeline.py:294 inside a captured graph */
 int mf_broadcast_from_table_f32(const float* table, const int32_t* step_dev, int32_t step, float* out, int n, void* stream);
 /* out[b][:] = table[step][cols[b]][:] for a [S][ncol][row_len] table, step = *step_dev (or `step`): the per-iteration gather of the
  * embedding rows UNet.precompute_embeddings hoisted out of the loop (unet2.py:229-241, conv_blocks.py:340-353), usable inside a captured graph. */
 int mf_gather_step_rows_f32(const float* table, const int64_t* cols, const int32_t* step_dev, int32_t step, int ncol, int64_t row_len,
                             float* out, int B, void* stream);
+/* Up to three such gathers in ONE launch (ABI 220): the embedding rows, the local-embedder rows and their bounds share `cols` and the step. */
+int mf_gather_step_rows3_f32(const float* const* tables, const int64_t* row_lens, float* const* outs, int n_tables, const int64_t* cols,
+                             const int32_t* step_dev, int32_t step, int ncol, int B, void* stream);
 /* *counter += inc (one thread); lets a captured graph advance its own step index. */
 int mf_counter_add_i32(int32_t* counter, int32_t inc, void* stream);
 

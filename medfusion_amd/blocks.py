@@ -50,6 +50,7 @@ class _Packed:
         self._w3 = None
         self._wb = None
         self._wh = None
+        self._l1 = {}
         self._subpixel = subpixel
 
     def get(self, weight: torch.Tensor) -> torch.Tensor:
@@ -62,6 +63,7 @@ class _Packed:
             self._w3 = None
             self._wb = None
             self._wh = None
+            self._l1 = {}
             self._key = key
         return self._w
 
@@ -71,6 +73,18 @@ class _Packed:
         if self._wh is None:
             self._wh = K.split_weight_f16x2(wp)   # (pairs scaled by max |w|, that max)
         return self._wh
+
+    def l1(self, weight: torch.Tensor, c1: int):
+        """(largest L1 norm of a filter over input channels [0, c1), ... over [c1, Cin)) of the packed weights: the operand side of the
+        DERIVED output bound of mf_conv2d_f16x2_pairs_out (|y| <= bound(x1) l1[0] + bound(x2) l1[1] + max |bias|).  Load-time host sync, cached."""
+        wp = self.get(weight)
+        ent = self._l1.get(c1)
+        if ent is None:
+            a = wp[..., :c1].abs().sum(dim=(-3, -2, -1)).max()
+            b = wp[..., c1:].abs().sum(dim=(-3, -2, -1)).max() if c1 < wp.shape[-1] else torch.zeros((), device=wp.device)
+            # (a hair above the fp32 sums: they feed an UPPER bound)
+            ent = self._l1[c1] = (float(a.item()) * (1.0 + 1e-5), float(b.item()) * (1.0 + 1e-5))
+        return ent
 
     def get_bf16(self, weight: torch.Tensor) -> torch.Tensor:
         """the same weights rounded to bf16 (opt-in MF_CONV_BF16)"""
@@ -88,6 +102,7 @@ class _Packed:
 
 
 PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"   # (A/B switch of the pairs-only apply output)
+DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
 #   5 (default) fp32 through PAIRS of fp16: 23-bit operands with a per-sample power-of-two scale, three product terms on the fp16 matrix
@@ -117,6 +132,8 @@ class Conv(nn.Module):
         self._packed = _Packed()
         self._packed_sub = _Packed(subpixel=True)
         self._descs = {}
+        self._pairs_out = {}
+        self._bmax = (None, 0.0)
 
     def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5):
         """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel"""
@@ -134,6 +151,17 @@ class Conv(nn.Module):
         pk = self._packed_sub if d.upsample == 2 else self._packed
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
+            if measure_out and out is None and DERIVED_OUT_BOUNDS:
+                # an output that feeds convolutions un-normalised (down- / up-sampling): its fp16-pair form straight from the epilogue, under
+                # a bound derived from the operands -- no measuring pass, no split launch in front of the consumers
+                po = self._pairs_out.get(key)
+                if po is None:
+                    po = self._pairs_out[key] = K.conv_pairs_out_ok(d)
+                if po:
+                    bkey = (self.bias._version, self.bias.data_ptr())
+                    if self._bmax[0] != bkey:
+                        self._bmax = (bkey, float(self.bias.detach().abs().max().item()))
+                    return K.conv2d_f16x2_pairs_out(x1, wh, self.bias, d, pk.l1(self.weight, c1), self._bmax[1], x2=x2, pinned=pinned)
             return K.conv2d_f16x2(x1, wh, self.bias, d, x2=x2, out=out, measure_out=measure_out, pinned=pinned)
         ho, wo = K.conv_out_hw(d)
         if parts > 0:

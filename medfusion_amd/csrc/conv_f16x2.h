@@ -99,6 +99,12 @@ struct ConvP2 {
   float* handoff;       // [tiles][2 (splitk - 1) slots][BM x BN floats]
   unsigned* sync;       // [tiles][splitk - 1] counters, zero between launches (the second arriver of a pair resets its counter)
   FuseP fz;
+  // the output ALSO as fp16 pairs, scaled per sample by a bound DERIVED from the operands (round 4): |y| <= bound(x1) wl1_1 + bound(x2) wl1_2 + bmax,
+  // wl1 = the largest L1 norm of a filter over the source's channels -- no measuring pass, no separate split launch behind the convolutions
+  // whose output feeds convolutions un-normalised (down- / up-sampling).  Final-value workgroups only (splitk == 1 or tree).
+  void* y_pairs;
+  float* y_pair_bound;   // [N] written
+  float wl1_1, wl1_2, bmax;
 #if MFC2_HZ & (256 | 512)
   float* dbg;           // diagnostic builds: [tiles][waves][TM][TN][16][64] the accumulators of the surviving workgroup right behind the tree
 #endif

@@ -380,9 +380,28 @@ int mf_conv2d_f16x2_fuse_words(const MfConvDesc* d, int G) {
   return fuse_tiles_per_sample(d, pl, G) > 0 ? 2 * d->N : 0;
 }
 
+struct PairsOut { void* y_split; float* y_bound; float wl1_1, wl1_2, bmax; };
 static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                            float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
-                           const MfGnFuse* fz, const MfConvDesc* d, void* stream);
+                           const MfGnFuse* fz, const MfConvDesc* d, void* stream, const PairsOut* po = nullptr);
+
+// can the epilogue of this plan write the output's fp16-pair form itself (final values in the launch: no reducer pass behind it)?
+int mf_conv2d_f16x2_pairs_out_ok(const MfConvDesc* d) {
+  Plan2 pl;
+  if (!d || !pair_precision(d->precision) || make_plan2(d, &pl) != MF_OK || !pl.ok || d->Cout % 8) return 0;
+  return (pl.splitk == 1 || tree_possible(d, pl)) ? 1 : 0;
+}
+
+int mf_conv2d_f16x2_pairs_out(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* y_split, float* y_bound_out,
+                              const float* x1_bound, const float* x2_bound, float w_bound, float w_l1_1, float w_l1_2, float bias_max, void* workspace,
+                              size_t workspace_bytes, uint32_t* sync, const MfConvDesc* d, void* stream) {
+  MF_REQUIRE(y && y_split && y_bound_out && x1_bound, MF_EINVAL, "conv(f16x2, pairs out): y, y_split, y_bound_out and x1_bound are required");
+  MF_REQUIRE(d && (d->C2 == 0 || x2_bound), MF_EINVAL, "conv(f16x2, pairs out): x2_bound with a second source");
+  MF_REQUIRE(mf_conv2d_f16x2_pairs_out_ok(d), MF_EUNSUPPORTED, "conv(f16x2, pairs out): this plan reduces split-K behind the launch (mf_conv2d_f16x2_pairs_out_ok == 0)");
+  MF_REQUIRE(w_l1_1 >= 0.f && w_l1_2 >= 0.f && bias_max >= 0.f, MF_EINVAL, "conv(f16x2, pairs out): norms must be >= 0");
+  const PairsOut po{y_split, y_bound_out, w_l1_1, w_l1_2, bias_max};
+  return conv_f16x2_impl(x1s, x2s, ws, bias, y, x1_bound, x2_bound, w_bound, nullptr, workspace, workspace_bytes, sync, nullptr, 0, nullptr, d, stream, &po);
+}
 
 int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                     float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
@@ -406,7 +425,7 @@ int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, c
 
 static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                            float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
-                           const MfGnFuse* fz, const MfConvDesc* d, void* stream) {
+                           const MfGnFuse* fz, const MfConvDesc* d, void* stream, const PairsOut* po) {
   MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2 (or the opt-in MF_CONV_F16)");
   Plan2 pl;
   int rc = make_plan2(d, &pl);
@@ -438,6 +457,8 @@ static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, con
 #if MFC2_HZ & (256 | 512)
   p.dbg = g_conv_dbg;
 #endif
+  p.y_pairs = po ? po->y_split : nullptr; p.y_pair_bound = po ? po->y_bound : nullptr;
+  p.wl1_1 = po ? po->wl1_1 : 0.f; p.wl1_2 = po ? po->wl1_2 : 0.f; p.bmax = po ? po->bmax : 0.f;
   memset(&p.fz, 0, sizeof(p.fz));
   if (fz) {
     const int tps = fuse_tiles_per_sample(d, pl, G);

@@ -405,6 +405,37 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     return (out, partial) if gn_groups else out
 
 
+def conv_pairs_out_ok(d: L.MfConvDesc) -> bool:
+    return bool(L.load().mf_conv2d_f16x2_pairs_out_ok(C.byref(d)))
+
+
+def conv2d_f16x2_pairs_out(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, l1, bias_max: float, x2: Optional[torch.Tensor] = None,
+                           pinned=None) -> torch.Tensor:
+    """the fp16-pair convolution writing its output as fp32 AND as fp16 pairs under a bound derived from the operands
+    (mf_conv2d_f16x2_pairs_out): l1 = (largest filter L1 norm over the channels of x1, ... of x2), bias_max = max |bias|.  The result carries
+    its mirror and bound like the output of gn_apply(split=True): no measuring pass, no split launch in front of its consumers."""
+    wh, wmax = w_split
+    _gpu(x1, x2, wh, bias)
+    lib = L.load()
+    x1s, b1 = split_of(x1), bound_of(x1)
+    x2s, b2 = (split_of(x2), bound_of(x2)) if x2 is not None else (None, None)
+    ho, wo = conv_out_hw(d)
+    out = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.float32, device=x1.device)
+    outs = torch.empty((d.N, ho, wo, d.Cout), dtype=torch.int32, device=x1.device)
+    ob = torch.empty((d.N,), dtype=torch.float32, device=x1.device)
+    if pinned is None:
+        pinned = (lib.mf_conv2d_workspace_bytes(C.byref(d)), 0, lib.mf_conv2d_f16x2_sync_words(C.byref(d)))
+    need, _, words = pinned
+    ws = Workspace.get(need, x1.device) if need else None
+    sync = SyncWords.get(words, x1.device) if words else None
+    rc = lib.mf_conv2d_f16x2_pairs_out(x1s.data_ptr(), _ptr(x2s), wh.data_ptr(), _ptr(bias), out.data_ptr(), outs.data_ptr(), ob.data_ptr(), b1.data_ptr(), _ptr(b2),
+                                       wmax, float(l1[0]), float(l1[1]), float(bias_max), _ptr(ws), need, _ptr(sync), C.byref(d), stream())
+    L.check(rc, "mf_conv2d_f16x2_pairs_out")
+    out._mf_split, out._mf_bound = outs, ob
+    _stamp(out)
+    return out
+
+
 def conv_fuse_words(d: L.MfConvDesc, G: int) -> int:
     """rendezvous words mf_conv2d_f16x2_gn_apply needs for `d` followed by a G-group GroupNorm; 0: this convolution cannot apply it itself
     (capability; whether blocks.py uses the form is Rendezvous.disabled / FUSE_MIN_HW)"""
@@ -721,6 +752,32 @@ def sched_step(args: L.MfSchedArgs, outputs=()) -> None:
     for t in outputs:
         drop_split(t)
     L.check(L.load().mf_sched_step_f32(C.byref(args), stream()), "mf_sched_step_f32")
+
+
+def sched_step_philox(args: L.MfSchedArgs, seed: int, draw_base: int, draw_stride: int, sample_offset: int, B: int, counter: torch.Tensor, outputs=()) -> None:
+    """the tail of a denoise iteration in one launch (mf_sched_step_philox_f32): both noise draws in registers, the scheduler step, the
+    step counter += 1.  counter: int32 [2] on the device = (step, ticket word)."""
+    _gpu(counter)
+    for t in outputs:
+        drop_split(t)
+    L.check(L.load().mf_sched_step_philox_f32(C.byref(args), seed & 0xFFFFFFFFFFFFFFFF, draw_base, draw_stride, sample_offset, B, counter.data_ptr(),
+                                              counter.data_ptr() + 4, stream()), "mf_sched_step_philox_f32")
+
+
+def gather_step_rows_multi(tables, step, cols: torch.Tensor):
+    """gather_step_rows for up to three [S, NCOL, L_i] tables that share `cols` and the step, in ONE launch -> list of [B, L_i]"""
+    _gpu(cols, *tables)
+    n = len(tables)
+    assert 1 <= n <= 3 and all(t.is_contiguous() and t.shape[:2] == tables[0].shape[:2] for t in tables) and cols.dtype == torch.int64 and cols.is_contiguous()
+    B, ncol = cols.shape[0], tables[0].shape[1]
+    outs = [torch.empty((B, t.shape[2]), dtype=torch.float32, device=t.device) for t in tables]
+    tp = (L.c_fp * n)(*[t.data_ptr() for t in tables])
+    op = (L.c_fp * n)(*[o.data_ptr() for o in outs])
+    rl = (C.c_int64 * n)(*[t.shape[2] for t in tables])
+    dev_step = isinstance(step, torch.Tensor)
+    rc = L.load().mf_gather_step_rows3_f32(tp, rl, op, n, cols.data_ptr(), step.data_ptr() if dev_step else None, 0 if dev_step else int(step), ncol, B, stream())
+    L.check(rc, "mf_gather_step_rows3_f32")
+    return outs
 
 
 def gather_step_rows(table: torch.Tensor, step, cols: torch.Tensor) -> torch.Tensor:

@@ -59,6 +59,8 @@ _SIGS = {
     "mf_split_f16x2_slots": (_I, [c_fp, c_fp, c_fp, _I, c_fp, _I, _I64, c_fp]),
     "mf_conv2d_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_sync_words": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_f16x2_pairs_out_ok": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_f16x2_pairs_out": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, _F, _F, _F, c_fp, _SZ, c_fp, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_fuse_words": (_I, [C.POINTER(MfConvDesc), _I]),
     "mf_conv2d_f16x2_gn_apply": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfGnFuse), C.POINTER(MfConvDesc), c_fp]),
     "mf_maxabs_rows_slots": (_I, [_I64]),
@@ -83,6 +85,8 @@ _SIGS = {
     "mf_learned_sinusoidal_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, c_fp]),
     "mf_embedding_add_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
     "mf_sched_step_f32": (_I, [C.POINTER(MfSchedArgs), c_fp]),
+    "mf_sched_step_philox_f32": (_I, [C.POINTER(MfSchedArgs), _U64, C.c_int32, C.c_int32, _I64, _I, c_fp, c_fp, c_fp]),
+    "mf_gather_step_rows3_f32": (_I, [C.POINTER(c_fp), C.POINTER(_I64), C.POINTER(c_fp), _I, c_fp, c_fp, C.c_int32, _I, _I, c_fp]),
     "mf_broadcast_from_table_f32": (_I, [c_fp, c_fp, C.c_int32, c_fp, _I, c_fp]),
     "mf_gather_step_rows_f32": (_I, [c_fp, c_fp, c_fp, C.c_int32, _I, _I64, c_fp, _I, c_fp]),
     "mf_rows_axpby_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I, _I64, _I, _F, _F, c_fp]),

@@ -339,8 +339,9 @@ class DiffusionPipeline(nn.Module):
             raise RuntimeError("use_graph=True needs the device Philox noise source (a host generator cannot be captured)")
         dev, B = x_t.device, x_t.shape[0]
         t_table = torch.tensor(rev, dtype=torch.float32, device=dev)
-        step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        t_cur = torch.empty(B, dtype=torch.float32, device=dev)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)    # (step, ticket word of the fused tail launch)
+        step_dev = counter[:1]
+        t_cur = torch.zeros(B, dtype=torch.float32, device=dev)   # (filled per iteration only when the estimator reads t: not with hoisted embeddings)
         n_post, n_ddim, x0 = torch.empty_like(x_t), torch.empty_like(x_t), torch.empty_like(x_t)
         stride = 2 if use_ddim else 1
         base = noise.draw_index  # draws consumed so far (x_T)
@@ -349,9 +350,21 @@ class DiffusionPipeline(nn.Module):
         emb_tab = self._hoisted_embeddings(self._estimator(), t_table, condition, un_cond, B, dev)
         emb = None if emb_tab is None else (emb_tab[0], step_dev, emb_tab[1], emb_tab[2], emb_tab[3])   # rows of iteration *step_dev, gathered on the device
 
+        # the tail of an iteration -- posterior draw, DDIM draw, scheduler step, counter += 1 -- as ONE launch (mf_sched_step_philox_f32: the same
+        # Philox quads and the same scheduler arithmetic, bit for bit), unless MEDFUSION_LOOP_TAIL=0 (A/B) or the latent is not a whole
+        # number of quads per sample
+        fused_tail = os.environ.get("MEDFUSION_LOOP_TAIL", "1") != "0" and (x_t.numel() // B) % 4 == 0
+
         def body():
-            K.broadcast_from_table(t_table, step_dev, t_cur)
+            if emb is None:   # (with the embedding rows hoisted out of the loop the estimator never reads t)
+                K.broadcast_from_table(t_table, step_dev, t_cur)
             pred, pred_uncond, pred_var = self._predict(x_t, t_cur, condition, None if not self.use_self_conditioning else x0, g, un_cond, emb=emb)
+            if fused_tail:
+                a = L.MfSchedArgs(x_t.data_ptr(), pred.data_ptr(), None if pred_uncond is None else pred_uncond.data_ptr(),
+                                  None if pred_var is None else pred_var.data_ptr(), None, None, 0, x_t.data_ptr(), x0.data_ptr(), None, table.data_ptr(),
+                                  step_dev.data_ptr(), 0, objective, clip, g, x_t.numel())
+                K.sched_step_philox(a, noise._seed, base, stride, noise.sample_offset, B, counter, outputs=(x_t, x0))
+                return pred
             noise.draw_indexed(n_post, base, stride, step_dev)
             if use_ddim:
                 noise.draw_indexed(n_ddim, base + 1, stride, step_dev)
@@ -365,7 +378,8 @@ class DiffusionPipeline(nn.Module):
         def first_iteration():
             # Q11: with self-conditioning the first call sees self_cond=None -> run it eagerly in that form
             if self.use_self_conditioning:
-                K.broadcast_from_table(t_table, step_dev, t_cur)
+                if emb is None:
+                    K.broadcast_from_table(t_table, step_dev, t_cur)
                 pred, pu, pv = self._predict(x_t, t_cur, condition, None, g, un_cond, emb=emb)
                 noise.draw_indexed(n_post, base, stride, step_dev)
                 if use_ddim:

@@ -268,11 +268,12 @@ class UNet(nn.Module):
     def step_embeddings(table, i, cols: torch.Tensor):
         """(emb [B,E] | None, local_all [B, sum Cout]) of loop iteration i for rows with table columns `cols`.
         i: a host int, or the device int32 step counter of a captured graph (mf_gather_step_rows_f32 reads it on the device)."""
-        emb = K.gather_step_rows(table["emb"], i, cols) if table["need_emb"] else None
-        local = K.gather_step_rows(table["local"], i, cols)
-        if "local_bound" in table:
-            local._mf_bound = K.gather_step_rows(table["local_bound"], i, cols).view(-1)
-        return emb, local
+        names = (["emb"] if table["need_emb"] else []) + ["local"] + (["local_bound"] if "local_bound" in table else [])
+        got = dict(zip(names, K.gather_step_rows_multi([table[k] for k in names], i, cols)))    # ONE launch for the two or three gathers
+        local = got["local"]
+        if "local_bound" in got:
+            local._mf_bound = got["local_bound"].view(-1)
+        return got.get("emb"), local
 
     @torch.no_grad()
     def forward_cfg_pair(self, x_t, t, condition, un_cond, emb_cache=None):

@@ -417,6 +417,47 @@ def test_sched_step_bit_exact(dev, objective, clip):
         assert torch.equal(out.cpu(), want), (i, "x_t")
 
 
+@pytest.mark.parametrize("objective,use_ddim,cfg", [("x_T", True, False), ("x_T", True, True), ("x_0", True, False), ("x_T", False, False)])
+def test_loop_tail_in_one_launch_equals_the_four_launches(dev, objective, use_ddim, cfg):
+    """mf_sched_step_philox_f32 (round 4: both noise draws in registers + the scheduler step + the step counter, one launch) against
+    mf_philox_normal_f32 x 2 + mf_sched_step_f32 + mf_counter_add_i32 over a whole 7-iteration loop driven by the device counter: x_t and
+    x_0 bit-identical at every iteration, the counter advances by one per launch, the ticket word returns to zero; a batch with a row offset
+    (a shard of a multi-GPU batch) draws the rows of the global batch."""
+    import medfusion_amd as M
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    psch = M.GaussianNoiseScheduler(**R.published_scheduler_kwargs())
+    ts, steps = psch.loop_timesteps(7, use_ddim)
+    table = psch.upload_records(psch.step_records(ts, use_ddim), dev)
+    B, shape, seed, off, base = 5, (5, 8, 16, 24), 0x1234567890ABCDEF, 3, 1
+    stride = 2 if use_ddim else 1
+    xa = _rand("lt_x", shape).to(dev)
+    xb = xa.clone()
+    x0a, x0b = torch.empty_like(xa), torch.empty_like(xa)
+    n_post, n_ddim = torch.empty_like(xa), torch.empty_like(xa)
+    ca = torch.zeros(1, dtype=torch.int32, device=dev)
+    cb = torch.zeros(2, dtype=torch.int32, device=dev)
+    obj, g = 0 if objective == "x_T" else 1, 3.0
+    for i in range(steps):
+        pred = _rand(f"lt_p{i}", shape).to(dev)
+        pu = _rand(f"lt_u{i}", shape).to(dev) if cfg else None
+        # four launches
+        K.philox_normal(n_post, seed, base, off, step_dev=ca, draw_stride=stride)
+        if use_ddim:
+            K.philox_normal(n_ddim, seed, base + 1, off, step_dev=ca, draw_stride=stride)
+        a = L.MfSchedArgs(xa.data_ptr(), pred.data_ptr(), None if pu is None else pu.data_ptr(), None, n_post.data_ptr(), n_ddim.data_ptr() if use_ddim else None, 0,
+                          xa.data_ptr(), x0a.data_ptr(), None, table.data_ptr(), ca.data_ptr(), 0, obj, 0, g, xa.numel())
+        K.sched_step(a, outputs=(xa, x0a))
+        K.counter_add(ca, 1)
+        # one launch
+        b = L.MfSchedArgs(xb.data_ptr(), pred.data_ptr(), None if pu is None else pu.data_ptr(), None, None, None, 0, xb.data_ptr(), x0b.data_ptr(), None,
+                          table.data_ptr(), cb.data_ptr(), 0, obj, 0, g, xb.numel())
+        K.sched_step_philox(b, seed, base, stride, off, B, cb, outputs=(xb, x0b))
+        assert torch.equal(xa, xb) and torch.equal(x0a, x0b), (i, objective, use_ddim)
+        assert cb.tolist() == [i + 1, 0] and int(ca.item()) == i + 1
+    assert bool(xa.isfinite().all())
+
+
 def test_sched_step_learned_variance(dev):
     import medfusion_amd as M
     from medfusion_amd import kernels as K
@@ -926,6 +967,40 @@ def test_gn_apply_pairs_only_output_and_residual_from_pairs(dev):
     assert float((diff / (a_full.abs() * 2.0 ** -22 + o_full.abs() * 2.0 ** -23 + 1e-30)).max()) <= 1.0
     assert float(diff.max()) > 0 or True
     assert torch.equal(o_po._mf_bound, o_full._mf_bound)
+
+
+@pytest.mark.parametrize("case", [(16, 32, 32, 256, 0, 256, 3, 2, 0, 0, 0), (16, 8, 8, 512, 0, 512, 3, 1, 2, 0, 0), (16, 16, 16, 512, 0, 512, 3, 2, 0, 53, 4),
+                                  (3, 10, 12, 32, 0, 64, 3, 2, 0, 0, 0), (2, 8, 8, 64, 32, 128, 3, 1, 0, 0, 0), (2, 16, 16, 64, 0, 128, 3, 1, 2, 0, 0),
+                                  (16, 8, 8, 1024, 0, 1024, 3, 1, 0, 52, 4)])
+def test_conv_pairs_out_under_a_derived_bound(dev, case):
+    """mf_conv2d_f16x2_pairs_out (round 4): the fp32 output is the plain convolution's, bit for bit; the bound is the derived one,
+    bound(x1) l1_1 + bound(x2) l1_2 + max |bias|, and really bounds |y|; the pair form written by the epilogue is EXACTLY the split of the
+    fp32 output under that bound (what mf_split_f16x2 gives) -- for stride-2 (BasicDown), sub-pixel (BasicUp), two-source and in-launch
+    split-K plans, with per-sample operand scales 2^+-20 apart."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, k, stride, ups, tile, sk = case
+    scale = torch.tensor([[1.0, 2.0 ** 20, 2.0 ** -20, 3.0][i % 4] for i in range(n)]).view(n, 1, 1, 1)
+    x = K.nchw_to_nhwc((_rand(f"px{case}", (n, c1, h, w)) * scale).to(dev))
+    x2 = K.nchw_to_nhwc((_rand(f"py{case}", (n, c2, h, w)) * scale * 0.5).to(dev)) if c2 else None
+    wt = _rand(f"pw{case}", (co, c1 + c2, k, k), 1.0 / np.sqrt((c1 + c2) * k * k)).to(dev)
+    b = _rand(f"pb{case}", (co,), 0.1).to(dev)
+    pad = R.monai_padding(k, stride)
+    wp = K.pack_upconv_weight(wt) if ups == 2 else K.pack_conv_weight(wt)
+    wh = K.split_weight_f16x2(wp)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, stride, pad, ups, tile_hint=tile, splitk_hint=sk, precision=5)
+    assert K.conv_f16x2_ok(d) and K.conv_pairs_out_ok(d), case
+    l1 = (float(wp[..., :c1].abs().sum(dim=(-3, -2, -1)).max()) * (1 + 1e-5), float(wp[..., c1:].abs().sum(dim=(-3, -2, -1)).max()) * (1 + 1e-5) if c2 else 0.0)
+    bmax = float(b.abs().max())
+    got = K.conv2d_f16x2_pairs_out(x, wh, b, d, l1, bmax, x2=x2)
+    ref = K.conv2d_f16x2(x, wh, b, d, x2=x2)
+    assert torch.equal(got, ref), case
+    want_bound = K.bound_of(x) * l1[0] + (K.bound_of(x2) * l1[1] if c2 else 0.0) + bmax
+    assert torch.allclose(got._mf_bound, want_bound, rtol=1e-6, atol=0), case
+    assert bool((got._mf_bound >= ref.abs().amax(dim=(1, 2, 3))).all()), "the derived bound does not bound the output"
+    slack = (got._mf_bound / ref.abs().amax(dim=(1, 2, 3))).max()
+    assert float(slack) < 2.0 ** 12, float(slack)            # a few binades, far inside the 2^28 the pair format tolerates
+    assert torch.equal(got._mf_split, K.split_f16x2(ref, got._mf_bound)), case
+    assert torch.equal(got, K.conv2d_f16x2_pairs_out(x, wh, b, d, l1, bmax, x2=x2))   # deterministic
 
 
 FUSED_CASES = [
