@@ -319,6 +319,8 @@ def main():
                         use_ddim=wl["use_ddim"], **({} if cond is None else dict(guidance_scale=wl["guidance"], un_cond=None)))
         tab = p.table()
         ms, n, fl, alg_bytes, ex = tab["conv_igemm"]
+        if "conv_gn_fused" in tab:   # (opt-in MEDFUSION_FUSED_APPLY=1: those launches also hold the GroupNorm-apply work -- counted whole)
+            ms, n, fl, alg_bytes, ex = (a + b for a, b in zip(tab["conv_igemm"], tab["conv_gn_fused"]))
         total_ms = sum(v[0] for v in tab.values())
         alg = fl / (ms * 1e-3) / 1e12     # algorithmic FLOPs of the reference convolutions / their launch time
         exe = ex / (ms * 1e-3) / 1e12     # FLOPs the matrix pipe executes: terms per product x the MACs actually done (sub-pixel up-convs: 4/9)

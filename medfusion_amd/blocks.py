@@ -135,7 +135,7 @@ class Conv(nn.Module):
         self._pairs_out = {}
         self._bmax = (None, 0.0)
 
-    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5):
+    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5, derive_out=False):
         """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel"""
         key = ("f16x2", n, h, w, c1, c2, gn_groups, prec)
         ent = self._descs.get(key)
@@ -151,9 +151,13 @@ class Conv(nn.Module):
         pk = self._packed_sub if d.upsample == 2 else self._packed
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
-            if measure_out and out is None and DERIVED_OUT_BOUNDS:
+            if derive_out and out is None and DERIVED_OUT_BOUNDS:
                 # an output that feeds convolutions un-normalised (down- / up-sampling): its fp16-pair form straight from the epilogue, under
-                # a bound derived from the operands -- no measuring pass, no split launch in front of the consumers
+                # a bound derived from the operands -- no measuring pass, no split launch in front of the consumers.  ONLY where the bound
+                # does not propagate: a derived bound sits ~2^11 above the true maximum, harmless for one hop (the pair format keeps its
+                # 23 bits down to 2^-28 of the bound) but it compounds -- derived from derived along the residual stream (conv_res ->
+                # apply -> conv_res ...) it reached 2^44 x the data after seven blocks and the pairs lost their bits (scripts/debug_derived.py,
+                # round 4).  The consumers of a down- / up-sampled tensor are a GroupNorm'd convolution and a conv_res that MEASURES: both reset.
                 po = self._pairs_out.get(key)
                 if po is None:
                     po = self._pairs_out[key] = K.conv_pairs_out_ok(d)
@@ -203,9 +207,11 @@ class Conv(nn.Module):
                                        residual=residual, emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, pinned=pinned)
 
     def forward(self, x: Act, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out=None, rows: Optional[slice] = None, gn_groups: int = 0,
-                gn_eps: float = 1e-5, measure_out: bool = False):
+                gn_eps: float = 1e-5, measure_out: bool = False, derive_out: bool = False):
         """gn_groups > 0: also return the statistics of the GroupNorm that follows -> (y, stats [N,G,2]).
-        measure_out: in the fp16-pair mode, also measure the per-sample max |y| (y feeds a convolution or a residual add un-normalised)."""
+        measure_out: in the fp16-pair mode, also measure the per-sample max |y| (y feeds a convolution or a residual add un-normalised).
+        derive_out: ... or, where the plan allows, write y's fp16-pair form in the epilogue under a bound DERIVED from the operands (see
+        _forward_f16x2; only for tensors whose bound does not propagate: the outputs of down- / up-sampling)."""
         x1, x2 = _split(x)
         if in_layout == L.LAYOUT_NCHW:
             n, c1, h, w = x1.shape
@@ -220,7 +226,7 @@ class Conv(nn.Module):
                                f"reduced precisions 4 (bf16) / 6 (fp16)")
         if prec in (5, 6):
             if rows is None and in_layout == L.LAYOUT_NHWC and out_layout == L.LAYOUT_NHWC:
-                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec)
+                r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec, derive_out)
                 if r is not None:
                     return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
@@ -452,7 +458,7 @@ class BasicDown(nn.Module):
     def forward(self, x, emb=None):
         if self.learnable:
             if not self.use_res:
-                return self.down_op(x, measure_out=f16x2_mode())
+                return self.down_op(x, measure_out=f16x2_mode(), derive_out=True)
             if isinstance(x, (tuple, list)):
                 raise RuntimeError("BasicDown(use_res=True) takes one tensor")
             return K.pixel_unshuffle2_add(x, self.down_op(x))   # (the sum is measured by its first fp16-pair consumer)
@@ -478,7 +484,7 @@ class BasicUp(nn.Module):
     def forward(self, x, emb=None):
         if self.learnable:
             if not self.use_res:
-                return self.up_op(x, measure_out=f16x2_mode())
+                return self.up_op(x, measure_out=f16x2_mode(), derive_out=True)
             if isinstance(x, (tuple, list)):
                 raise RuntimeError("BasicUp(use_res=True) takes one tensor")
             return K.pixel_shuffle2_add(x, self.up_op(x))

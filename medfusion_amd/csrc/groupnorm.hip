@@ -5,6 +5,7 @@
 // combined in fp64 (a group of the VAE's 256x256 level holds 524 288 elements: E[x^2]-E[x]^2 in fp32
 // would lose the parity margin -- SURVEY §7 hard parts).
 #include "common.h"
+#include <stdlib.h>
 #include "gn_partial.h"
 
 using namespace mf;
@@ -413,7 +414,10 @@ int mf_gn_apply_from_partials_pairs_f32(const float* x, const double* gn_partial
   const long total_blocks = ((long)N * per4 + 255) / 256;
   const int U = total_blocks >= 4 * 1024 ? 4 : total_blocks >= 2 * 1024 ? 2 : 1;
   long bps = (per4 + 256 * U - 1) / (256 * U);
-  const long cap = (256 * 8 + N - 1) / N;   // ~8 blocks per CU over the whole launch
+  // workgroups per CU over the whole launch: every workgroup reduces the sample's records before it starts (~3 us), so FEWER, fatter ones
+  // amortise it -- MF_GN_BLOCKS_PER_CU (read once; A/B knob)
+  static const int per_cu = [] { const char* e = getenv("MF_GN_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v > 32 ? 32 : v; }();
+  const long cap = (256 * per_cu + N - 1) / N;
   if (bps > cap) bps = cap;
   const GnSplit sp{out_split, nullptr, res_bound, emb_bound, bconst, out_bound, res_bound ? nullptr : res_bound_slots, res_nslots, residual_pairs};
   const double count = (double)HW * (C / G);
