@@ -127,6 +127,7 @@ def cpu_model() -> str:
 
 
 MEASURE_ALL_THREADS = False
+CHECK = {}
 
 
 def cpu_baseline(classes):
@@ -148,13 +149,14 @@ def cpu_baseline(classes):
         unet(x, t)  # warm-up
         t0 = time.perf_counter()
         for _ in range(3):
-            unet(x, t)
+            y_unet = unet(x, t)[0]
         t_unet = (time.perf_counter() - t0) / 3
         z = x[:1]
         vae.decode(z)
         t0 = time.perf_counter()
-        vae.decode(z)
+        y_dec = vae.decode(z)
         t_dec = time.perf_counter() - t0
+        CHECK.update(x=x, t=t, y_unet=y_unet, z=z, y_dec=y_dec)   # (the timed evaluations double as the checker of the GPU path: parity_check)
         # SURVEY 8(d) says os.cpu_count() threads: measured here on ONE UNet forward at B=1, next to the same forward on `threads` (bounded: the
         # all-threads run was 50x slower in round 1 -- ATen's CPU convolutions oversubscribe -- which is why the baseline above uses `threads`)
         t1 = torch.full((1,), 500)
@@ -397,9 +399,22 @@ def main():
                                          "baseline_config": {"cfg3_g1": "configs[2] per-GPU share (128 / 8), guidance 1", "cfg3_g8": "configs[2] per-GPU share, guidance 8 (2B-row UNet calls)",
                                                              "cfg4": "configs[3]", "cfg5": "configs[4] per-GPU share (32 / 4)"}[name]}})
         del pipes
-    cpu = None
+    cpu = parity = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline(wl["classes"])
+        if CHECK and wl["classes"] is None:
+            # the oracle evaluations that were just timed, as the CHECKER of what was benchmarked (same seeded weights): one UNet forward at
+            # B = 4 and one VAE decode through the product path on this device.  A number from a path that computes something else is no number
+            # (round 4: a bound-propagation bug produced finite, constant images at full speed) -- bench.py fails loudly instead of printing it.
+            from tests.util import relerr, relerr_rows
+            with torch.no_grad():
+                g_unet = pipe.noise_estimator(CHECK["x"].to(dev), CHECK["t"].to(dev), None)[0]
+                g_dec = pipe.latent_embedder.decode(CHECK["z"].to(dev))
+            e1, e2 = relerr_rows(g_unet, CHECK["y_unet"]), relerr(g_dec, CHECK["y_dec"])
+            parity = {"unet_forward_B4_per_sample_relerr": float(f"{e1:.3e}"), "vae_decode_relerr": float(f"{e2:.3e}"), "tolerance": 1e-4,
+                      "against": "the oracle (CPU restatement of the reference) on the same seeded weights and inputs", "ok": bool(e1 < 1e-4 and e2 < 1e-4)}
+            if not parity["ok"]:
+                raise SystemExit(f"bench.py: the benchmarked path FAILS its parity check against the oracle: {parity}")
 
     if rank == 0:
         gflop_img = GFLOP_PER_IMAGE_CFG2 if args.workload == "cfg2" and not args.ddim_steps else None
@@ -413,7 +428,7 @@ def main():
                                    f"{'uncond' if cond is None else 'cond %d-class g=%s' % (wl['classes'], wl['guidance'])}, decode to {8 * wl['latent'][1]}x{8 * wl['latent'][2]}",
                        "global_batch": n_global, "parallelism": f"dp{world} (batch rows sharded, 1 all-gather of images)" + (" -- TEST MODE: ranks share one GPU, gloo" if share else ""),
                        "world": world, "backend": (dist.get_backend() if world > 1 else None), "ms_per_step_by_rank": rank_ms, "cpu_pinning_rank0": pinned},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity_check": parity,
         }
         if alts:
             out["other_conv_arithmetic"] = alts
