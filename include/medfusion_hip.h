@@ -359,6 +359,9 @@ int mf_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, vo
 /* DiagonalGaussianDistribution (latent_embedders.py:22-27): z = mean + exp(0.5*clamp(logvar,-30,20)) * noise,
  * moments NCHW [N][2C][HW] -> z [N][C][HW] */
 int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float* z, int N, int C, int HW, void* stream);
+/* its KL term (latent_embedders.py:29-31; ABI 220): kl[0] = 0.5 * sum(mean^2 + exp(logvar) - 1 - logvar) / N, logvar clamped like above, fp64
+ * accumulation -- the `emb_loss` VAE.forward returns (:778), evaluation-time only */
+int mf_diag_gaussian_kl_f32(const float* moments, float* kl, int N, int C, int HW, void* stream);
 
 /* learnable_interpolation=False (ABI 210): BasicDown = nn.AvgPool2d(k, stride, get_padding(k, stride)) (conv_blocks.py:57-63; count_include_pad
  * like torch's default: the divisor counts the padding), BasicUp = F.interpolate(nearest-exact) to twice the size (conv_blocks.py:128-130).

@@ -156,6 +156,29 @@ __global__ void diag_gaussian_kernel(const float* __restrict__ mom, const float*
   z[i] = mean + sn;
 }
 
+// KL term of DiagonalGaussianDistribution (latent_embedders.py:29-31): 0.5 * sum(mean^2 + var - 1 - logvar) / N over the whole tensor, one
+// workgroup, fp64 accumulation (the evaluation-time VAE.forward: off the sampling path)
+__global__ __launch_bounds__(1024) void diag_gaussian_kl_kernel(const float* __restrict__ mom, float* __restrict__ out, int N, int C, int HW) {
+  __shared__ double red[16];
+  const long per = (long)C * HW, total = (long)N * per;
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const long n = i / per, r = i - n * per;
+    const float mean = mom[n * 2 * per + r];
+    const float logvar = fminf(fmaxf(mom[n * 2 * per + per + r], -30.0f), 20.0f);
+    acc += (double)(mean * mean) + (double)expf(logvar) - 1.0 - (double)logvar;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[0] = (float)(0.5 * s / (double)N);
+  }
+}
+
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
                                  long rows, int C, float eps) {
   // one wave per row
@@ -266,6 +289,14 @@ int mf_diag_gaussian_sample_f32(const float* moments, const float* noise, float*
   ProfScope ps(MF_FAM_MISC, s, 4.0 * total, 16.0 * total);
   MF_LAUNCH(diag_gaussian_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, moments, noise, z, N, C, HW);
   return check_launch("diag_gaussian");
+}
+
+int mf_diag_gaussian_kl_f32(const float* moments, float* kl, int N, int C, int HW, void* stream) {
+  MF_REQUIRE(moments && kl && N > 0 && C > 0 && HW > 0, MF_EINVAL, "diag_gaussian_kl: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_MISC, s, 6.0 * N * C * HW, 8.0 * N * C * HW);
+  MF_LAUNCH(diag_gaussian_kl_kernel, dim3(1), dim3(1024), 0, s, moments, kl, N, C, HW);
+  return check_launch("diag_gaussian_kl");
 }
 
 int mf_layernorm_f32(const float* x, const float* gamma, const float* beta, float* out, int64_t rows, int C, float eps, void* stream) {

@@ -915,6 +915,15 @@ def diag_gaussian_sample(moments_nchw: torch.Tensor, noise: torch.Tensor) -> tor
     return z
 
 
+def diag_gaussian_kl(moments_nchw: torch.Tensor) -> torch.Tensor:
+    """the KL term of DiagonalGaussianDistribution (latent_embedders.py:29-31) as a 0-dim device tensor"""
+    _gpu(moments_nchw)
+    n, c2, h, w = moments_nchw.shape
+    kl = torch.empty((1,), dtype=torch.float32, device=moments_nchw.device)
+    L.check(L.load().mf_diag_gaussian_kl_f32(moments_nchw.contiguous().data_ptr(), kl.data_ptr(), n, c2 // 2, h * w, stream()), "mf_diag_gaussian_kl_f32")
+    return kl.reshape(())
+
+
 # ----------------------------------------------------------------------------- launch timing
 _PROF_ACTIVE = [False]
 

@@ -104,6 +104,7 @@ _SIGS = {
     "mf_nchw_to_nhwc_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_nhwc_to_nchw_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_diag_gaussian_sample_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, c_fp]),
+    "mf_diag_gaussian_kl_f32": (_I, [c_fp, c_fp, _I, _I, _I, c_fp]),
     "mf_prof_enable": (_I, [_I]),
     "mf_prof_reset": (_I, []),
     "mf_prof_query": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

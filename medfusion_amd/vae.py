@@ -62,14 +62,7 @@ class VAE(nn.Module):
             raise RuntimeError("medfusion_amd.VAE runs on a ROCm device only (no CPU fallback)")
         K.SyncWords.reset(x.device)
 
-        def run():
-            h = self.inc(x.contiguous(), None, in_layout=L.LAYOUT_NCHW)
-            for enc in self.encoders:
-                h = enc(h)
-            h = self.out_enc[0](h)
-            return self.out_enc[1](h, out_layout=L.LAYOUT_NCHW)
-
-        moments = K.with_fused_fallback(x.device, run)
+        moments = K.with_fused_fallback(x.device, lambda: self._encode_moments(x))
         n, c2, hh, ww = moments.shape
         src = noise if noise is not None else default_noise()
         src.begin(n, x.device)
@@ -94,5 +87,35 @@ class VAE(nn.Module):
 
         return K.with_fused_fallback(z.device, run)
 
-    def forward(self, x_in):
-        raise NotImplementedError("VAE.forward is the training pass (out of scope); use encode()/decode()")
+    def _encode_moments(self, x):
+        h = self.inc(x.contiguous(), None, in_layout=L.LAYOUT_NCHW)
+        for enc in self.encoders:
+            h = enc(h)
+        h = self.out_enc[0](h)
+        return self.out_enc[1](h, out_layout=L.LAYOUT_NCHW)
+
+    @torch.no_grad()
+    def forward(self, x_in: torch.Tensor, noise: Optional[NoiseSource] = None):
+        """latent_embedders.py:771-790 -- the reconstruction pass of the evaluation harness: (out [B,3,H,W], the deep-supervision outputs of
+        the coarser decoder levels (finest first, like the reference's `out_hor[::-1]`), the KL term of the quantizer).  Inference only:
+        the losses built on these (`_step`, :803-840) are training code and out of scope."""
+        if not x_in.is_cuda:
+            raise RuntimeError("medfusion_amd.VAE runs on a ROCm device only (no CPU fallback)")
+        K.SyncWords.reset(x_in.device)
+        src = noise if noise is not None else default_noise()
+
+        def run():
+            moments = self._encode_moments(x_in)
+            n, c2, hh, ww = moments.shape
+            src.begin(n, x_in.device)
+            z_q, _ = self.quantizer(moments, src.draw((n, c2 // 2, hh, ww)))
+            emb_loss = K.diag_gaussian_kl(moments)
+            out_hor = []
+            h = self.inc_dec(z_q.contiguous(), None, in_layout=L.LAYOUT_NCHW)
+            for i in range(len(self.decoders) - 1, -1, -1):
+                if i < len(self.outc_ver):
+                    out_hor.append(self.outc_ver[i](h, out_layout=L.LAYOUT_NCHW))
+                h = self.decoders[i](h)
+            return self.outc(h, out_layout=L.LAYOUT_NCHW), out_hor[::-1], emb_loss
+
+        return K.with_fused_fallback(x_in.device, run)

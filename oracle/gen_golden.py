@@ -318,6 +318,28 @@ def case_vae():
     save("vae_tiny", z=z, x_dec=xa, img=img, z_enc=za, enc_seed=11)
 
 
+@torch.no_grad()
+def case_vae_forward():
+    """VAE.forward (latent_embedders.py:771-790, round 4): reconstruction, deep-supervision outputs, KL term -- the evaluation-time pass"""
+    kw = dict(R.tiny_vae_kwargs(), deep_supervision=2)
+    ref, ora = ref_vae(kw).eval(), R.VAE(**kw).eval()
+    synth_pair(ref, ora, "vae_fwd.")
+    img = S.synth_input("vae_fwd_img", (2, 3, 32, 32), 0.5)
+    import unittest.mock as um
+    nz = S.PhiloxNoise(13)
+    with um.patch.object(torch, "randn", side_effect=lambda shape, generator=None, device=None: nz(torch.empty(shape))):
+        oa, ha, ka = ref(img)
+    nz2 = S.PhiloxNoise(13)
+    ora.quantizer.noise_fn = lambda shape, device: nz2(torch.empty(shape))
+    ob, hb, kb = ora(img)
+    check_equal("vae_forward out", oa, ob)
+    assert len(ha) == len(hb) == 2
+    for i, (a, b) in enumerate(zip(ha, hb)):
+        check_equal(f"vae_forward hor{i}", a, b)
+    check_equal("vae_forward kl", ka.reshape(1), kb.reshape(1))
+    save("vae_forward", img=img, out=oa, hor0=ha[0], hor1=ha[1], kl=ka.reshape(1), seed=13)
+
+
 def build_pipes(unet_kw, vae_kw, sched_kw, tag, clip_x0=False, objective="x_T", estimate_variance=False, self_cond=False):
     rk = ref_unet_kwargs(unet_kw)
     ref = RefPipeline(noise_scheduler=RefScheduler, noise_estimator=RefUNet, latent_embedder=None,
@@ -418,7 +440,7 @@ def case_cfg1_published():
 
 if __name__ == "__main__":
     only = set(sys.argv[1:])
-    cases = [case_scheduler, case_embedders, case_learned_posemb, case_blocks, case_nonlearnable, case_use_res, case_attention, case_unets, case_vae, case_samples, case_cfg1_published]
+    cases = [case_scheduler, case_embedders, case_learned_posemb, case_blocks, case_nonlearnable, case_use_res, case_attention, case_unets, case_vae, case_vae_forward, case_samples, case_cfg1_published]
     for fn in cases:
         if only and fn.__name__ not in only:
             continue

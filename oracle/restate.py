@@ -585,6 +585,20 @@ class VAE(nn.Module):
             h = self.decoders[i - 1](h)
         return self.outc(h)
 
+    def forward(self, x_in):
+        """latent_embedders.py:771-790: the reconstruction pass -> (out, deep-supervision outputs coarse-to-fine reversed, KL term)"""
+        h = self.inc(x_in)
+        for enc in self.encoders:
+            h = enc(h)
+        z_q, emb_loss = self.quantizer(self.out_enc(h))
+        out_hor = []
+        h = self.inc_dec(z_q)
+        for i in range(len(self.decoders) - 1, -1, -1):
+            if i < len(self.outc_ver):
+                out_hor.append(self.outc_ver[i](h))
+            h = self.decoders[i](h)
+        return self.outc(h), out_hor[::-1], emb_loss
+
 
 # ----------------------------------------------------------------------------- scheduler
 class GaussianNoiseScheduler(nn.Module):

@@ -63,6 +63,20 @@ def test_embedders():
 
 
 @torch.no_grad()
+def test_vae_forward():
+    """VAE.forward (latent_embedders.py:771-790): reconstruction, deep-supervision outputs, KL term against the reference's own output"""
+    g = gold("vae_forward")
+    m = R.VAE(**dict(R.tiny_vae_kwargs(), deep_supervision=2)).eval()
+    S.synth_state_dict(m, "vae_fwd.")
+    nz = S.PhiloxNoise(int(g["seed"]))
+    m.quantizer.noise_fn = lambda shape, device: nz(torch.empty(shape))
+    out, hor, kl = m(T(g["img"]))
+    assert relerr(out, T(g["out"])) <= TOL and len(hor) == 2
+    assert relerr(hor[0], T(g["hor0"])) <= TOL and relerr(hor[1], T(g["hor1"])) <= TOL
+    assert abs(float(kl) - float(g["kl"][0])) <= 1e-5 * abs(float(g["kl"][0]))
+
+
+@torch.no_grad()
 def test_learned_sinusoidal_posemb():
     """time_embedder.py:31-49 against the reference's own output (even and odd emb_dim): the first column is t itself, bit for bit"""
     g = gold("learned_posemb")

@@ -144,6 +144,23 @@ def test_embedders_golden(dev):
     assert torch.equal(le.to(dev)(T(g["cond"]).to(dev)).cpu(), T(g["label64"]))
 
 
+def test_vae_forward_golden(dev):
+    """VAE.forward -- the evaluation-time reconstruction pass (latent_embedders.py:771-790): output, both deep-supervision outputs and the KL term
+    of the quantizer against what the REFERENCE returns for the same weights, image and injected noise"""
+    g = gold("vae_forward")
+    m = M.VAE(**dict(R.tiny_vae_kwargs(), deep_supervision=2))
+    S.synth_state_dict(m, "vae_fwd.")
+    m.to(dev).eval()
+    out, hor, kl = m(T(g["img"]).to(dev), noise=oracle_noise(int(g["seed"])))
+    assert out.shape == (2, 3, 32, 32) and len(hor) == 2
+    assert relerr(out, T(g["out"])) < TOL
+    assert relerr(hor[0], T(g["hor0"])) < TOL and relerr(hor[1], T(g["hor1"])) < TOL
+    assert abs(float(kl) - float(g["kl"][0])) < 1e-5 * abs(float(g["kl"][0]))
+    # decode(encode(x)) is the same reconstruction
+    z = m.encode(T(g["img"]).to(dev), noise=oracle_noise(int(g["seed"])))
+    assert relerr(m.decode(z), T(g["out"])) < TOL
+
+
 def test_learned_sinusoidal_posemb_golden(dev, conv_precision):
     """LearnedSinusoidalPosEmb (time_embedder.py:31-49) against the reference's output; and TimeEmbbeding refuses it the way the reference's
     first nn.Linear does (emb_dim + 1 features into Linear(emb_dim, ...))"""
