@@ -169,6 +169,11 @@ int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, c
                              float w_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
                              const MfGnFuse* f, const MfConvDesc* d, void* stream);
 
+/* The network input as an fp16-pair operand (ABI 220; the NCHW latent of unet2.py:246 / the image of latent_embedders.py:757): x NCHW
+ * [N][C][HW], C <= CP -> the pair form of the NHWC tensor [N][HW][CP] (CP % 32 == 0, channels C .. CP-1 zero) scaled per sample by its own
+ * max |x|, which the launch measures and publishes (bound_out[N]); one workgroup per sample (C * HW <= 2^18).  With the convolution's
+ * weights zero-padded to CP input channels (host, once) the input convolution runs on mf_conv2d_f16x2 like the rest of the network. */
+int mf_pack_nchw_pairs_f32(const float* x, void* out_pairs, float* bound_out, int N, int C, int HW, int CP, void* stream);
 /* The same convolution writing its output ALSO as fp16 pairs (ABI 220), for outputs that feed convolutions un-normalised (BasicDown /
  * BasicUp, conv_blocks.py:66,123-125): the per-sample scale comes from a bound DERIVED from the operands, |y[n]| <= x1_bound[n] w_l1_1 +
  * x2_bound[n] w_l1_2 + bias_max with w_l1 = max over the output channels of the L1 norm of the filter over that source's channels (host,

@@ -44,7 +44,8 @@ def _split(x: Act):
 class _Packed:
     """Lazily packed device copy of a conv weight, invalidated by in-place parameter updates."""
 
-    def __init__(self, subpixel: bool = False):
+    def __init__(self, subpixel: bool = False, pad_cin: int = 0):
+        self._pad_cin = pad_cin
         self._key = None
         self._w = None
         self._w3 = None
@@ -59,6 +60,8 @@ class _Packed:
             w = weight.detach()
             if w.dim() == 3:  # Conv1d [O, I, 1]
                 w = w.unsqueeze(-1)
+            if self._pad_cin and w.shape[1] < self._pad_cin:   # zero input channels up to pad_cin (load-time plumbing): the padded pair operand's zeros meet zeros
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, self._pad_cin - w.shape[1]))
             self._w = K.pack_upconv_weight(w) if self._subpixel else K.pack_conv_weight(w)
             self._w3 = None
             self._wb = None
@@ -102,6 +105,7 @@ class _Packed:
 
 
 PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"   # (A/B switch of the pairs-only apply output)
+INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "1") != "0"   # (A/B switch: the NCHW input convolution on the fp16-pair kernel)
 DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
@@ -131,12 +135,15 @@ class Conv(nn.Module):
         self.in_ch, self.out_ch, self.k, self.stride, self.pad, self.upsample = in_ch, out_ch, kernel_size, stride, padding, int(upsample)
         self._packed = _Packed()
         self._packed_sub = _Packed(subpixel=True)
+        self._packed_pad = _Packed(pad_cin=32)
+        self._pad_ok = {}
         self._descs = {}
         self._pairs_out = {}
         self._bmax = (None, 0.0)
 
-    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5, derive_out=False):
-        """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel"""
+    def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5, derive_out=False, cin_pad=0):
+        """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel.
+        cin_pad: the weights zero-padded to that many input channels (the input convolution on a padded pair operand)"""
         key = ("f16x2", n, h, w, c1, c2, gn_groups, prec)
         ent = self._descs.get(key)
         if ent is None:
@@ -148,7 +155,7 @@ class Conv(nn.Module):
         d, parts, ok, pinned = ent
         if not ok:
             return None
-        pk = self._packed_sub if d.upsample == 2 else self._packed
+        pk = self._packed_pad if cin_pad else (self._packed_sub if d.upsample == 2 else self._packed)
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
             if derive_out and out is None and DERIVED_OUT_BOUNDS:
@@ -229,6 +236,19 @@ class Conv(nn.Module):
                 r = self._forward_f16x2(x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec, derive_out)
                 if r is not None:
                     return r
+            if (INPUT_CONV_ON_PAIRS and rows is None and in_layout == L.LAYOUT_NCHW and out_layout == L.LAYOUT_NHWC and x2 is None and out is None
+                    and not gn_groups and not self.upsample and c1 < 32 and self.out_ch % 64 == 0 and c1 * h * w <= (1 << 18)
+                    and self._pad_ok.get((n, h, w, prec), True)):
+                # the network's input convolution (8 -> 256 at the UNet, 3 -> 64 at the VAE encoder): the NCHW input goes to a 32-channel
+                # fp16-pair operand in one small launch (measuring its own bound), the weights are zero-padded to 32 input channels once, and
+                # the convolution runs on the matrix cores, writing its output's pair form under a derived bound -- instead of the fp32
+                # direct kernel + a measuring pass + a split pass (27 + 5 + 8 us per iteration -> 4 + 14)
+                if (n, h, w, prec) not in self._pad_ok:   # (asked once per shape: is the padded convolution on the pair kernel at all?)
+                    self._pad_ok[(n, h, w, prec)] = K.conv_f16x2_ok(K.make_conv_desc(n, h, w, 32, 0, self.out_ch, self.k, self.stride, self.pad, 0, precision=prec))
+                if self._pad_ok[(n, h, w, prec)]:
+                    r = self._forward_f16x2(K.pack_nchw_pairs(x1, 32), None, n, h, w, 32, 0, None, 0, gn_eps, True, prec, True, cin_pad=32)
+                    if r is not None:
+                        return r
             prec = 1  # not on the fp16-pair kernel (edge convolutions, odd channel counts): the exact bf16-triplet / plain fp32 kernels
             K._need_f32(x1, x2)
         key = (n, h, w, c1, c2, in_layout, out_layout, rows.start if rows else None, gn_groups, prec)

@@ -1,10 +1,45 @@
 // edge_ops.hip -- per-row scaled combinations (the scheduler's tensor API with a timestep PER ROW) and image egress.
 // Streaming passes over small tensors; bit-exact against ATen / numpy elementwise chains (library built with -ffp-contract=off).
 #include "common.h"
+#include "split_f16.h"
 
 using namespace mf;
 
 namespace {
+
+// The network input as an operand of the fp16-pair convolution (round 4): x NCHW [N][C][HW] (C <= CP) -> the fp16-pair form of the NHWC tensor
+// [N][HW][CP], channels C .. CP-1 zero, scaled per sample by its own max |x| -- measured and applied in ONE launch (one workgroup per sample:
+// the latents of the sampling path hold 8 x 32 x 32 .. 8 x 64 x 64 values per sample), which also publishes bound_out[n].  With the weights
+// zero-padded to CP input channels the 8 -> 256 input convolution of the UNet runs on the matrix cores like every other one.
+__global__ __launch_bounds__(256) void pack_nchw_pairs_kernel(const float* __restrict__ x, sf_u32x4* __restrict__ out, float* __restrict__ bound_out, int C, int HW,
+                                                              int CP) {
+  __shared__ float sm[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* xn = x + (long)n * C * HW;
+  float m = 0.f;
+  for (int i = tid; i < C * HW; i += 256) m = fmaxf(m, fabsf(xn[i]));
+  m = wave_max(m);
+  if ((tid & 63) == 0) sm[tid >> 6] = m;
+  __syncthreads();
+  const float b = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  if (tid == 0) bound_out[n] = b;
+  const float sc = exp2i(-scale_exp_of(b));
+  const int octs = CP >> 3;
+  for (int i = tid; i < HW * octs; i += 256) {   // (octet-major: consecutive threads take consecutive pixels of one octet -> coalesced NCHW reads)
+    const int o = i / HW, px = i - o * HW;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = o * 8 + k;
+      v[k] = c < C ? xn[(long)c * HW + px] * sc : 0.f;
+    }
+    sf_u32x4 hi, lo;
+    split8_f16(sf_f32x4{v[0], v[1], v[2], v[3]}, sf_f32x4{v[4], v[5], v[6], v[7]}, hi, lo);
+    sf_u32x4* q = out + (((long)n * HW + px) * octs + o) * 2;
+    q[0] = hi;
+    q[1] = lo;
+  }
+}
 
 // out[b][i] = clamp?( (a[b]*x[b][i] + c[b]*y[b][i]) / d[b] );  y / c / d optional.  Each product and the sum are rounded
 // separately: a*x - b*y of gaussian_scheduler.py:121 is evaluated as a*x + (-b)*y, bit-identical.
@@ -172,6 +207,14 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_add_kernel(const float* __
 }
 
 extern "C" {
+
+int mf_pack_nchw_pairs_f32(const float* x, void* out_pairs, float* bound_out, int N, int C, int HW, int CP, void* stream) {
+  MF_REQUIRE(x && out_pairs && bound_out && N > 0 && C > 0 && HW > 0 && CP >= C && CP % 32 == 0, MF_EINVAL, "pack_nchw_pairs: bad args (C <= CP, CP %% 32 == 0)");
+  MF_REQUIRE((long)C * HW <= (1L << 18), MF_EUNSUPPORTED, "pack_nchw_pairs: one workgroup per sample -- at most 2^18 values per sample");
+  ProfScope ps(MF_FAM_MISC, (hipStream_t)stream, 0, 4.0 * N * (double)HW * (C + CP));
+  MF_LAUNCH(pack_nchw_pairs_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, reinterpret_cast<sf_u32x4*>(out_pairs), bound_out, C, HW, CP);
+  return check_launch("pack_nchw_pairs");
+}
 
 int mf_pixel_unshuffle2_add_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   MF_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, MF_EINVAL, "pixel_unshuffle2_add: bad args (H, W even)");

@@ -405,6 +405,21 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     return (out, partial) if gn_groups else out
 
 
+def pack_nchw_pairs(x_nchw: torch.Tensor, cp: int = 32) -> torch.Tensor:
+    """NCHW fp32 [N, C, H, W] (C <= cp) -> an NHWC [N, H, W, cp] tensor that exists ONLY as fp16 pairs (channels C.. zero), scaled per sample by
+    the max |x| the same launch measures (mf_pack_nchw_pairs_f32): the operand form of the network input"""
+    _gpu(x_nchw)
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device)     # (storage never written: pairs only)
+    outs = torch.empty((n, h, w, cp), dtype=torch.int32, device=x.device)
+    ob = torch.empty((n,), dtype=torch.float32, device=x.device)
+    L.check(L.load().mf_pack_nchw_pairs_f32(x.data_ptr(), outs.data_ptr(), ob.data_ptr(), n, c, h * w, cp, stream()), "mf_pack_nchw_pairs_f32")
+    out._mf_split, out._mf_bound, out._mf_pairs_only = outs, ob, True
+    _stamp(out)
+    return out
+
+
 def conv_pairs_out_ok(d: L.MfConvDesc) -> bool:
     return bool(L.load().mf_conv2d_f16x2_pairs_out_ok(C.byref(d)))
 

@@ -59,6 +59,7 @@ _SIGS = {
     "mf_split_f16x2_slots": (_I, [c_fp, c_fp, c_fp, _I, c_fp, _I, _I64, c_fp]),
     "mf_conv2d_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_sync_words": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_pack_nchw_pairs_f32": (_I, [c_fp, c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_conv2d_f16x2_pairs_out_ok": (_I, [C.POINTER(MfConvDesc)]),
     "mf_conv2d_f16x2_pairs_out": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, _F, _F, _F, c_fp, _SZ, c_fp, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_fuse_words": (_I, [C.POINTER(MfConvDesc), _I]),

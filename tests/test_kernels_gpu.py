@@ -1003,6 +1003,46 @@ def test_conv_pairs_out_under_a_derived_bound(dev, case):
     assert torch.equal(got, K.conv2d_f16x2_pairs_out(x, wh, b, d, l1, bmax, x2=x2))   # deterministic
 
 
+@pytest.mark.parametrize("case", [(16, 8, 32, 32, 256, 3), (2, 8, 64, 64, 256, 3), (3, 3, 20, 12, 64, 3), (2, 4, 8, 8, 128, 1)])
+def test_input_convolution_on_the_pair_kernel(dev, case):
+    """round 4: the NCHW network input goes to a zero-padded 32-channel fp16-pair operand in one launch (mf_pack_nchw_pairs_f32: the bound it
+    publishes is the sample's max |x|, its pairs are EXACTLY the split of the padded NHWC tensor under that bound), and the input convolution
+    (8 -> 256 at the UNet, 3 -> 64 at the VAE) runs on the fp16-pair kernel with zero-padded weights: against an fp64 convolution to the
+    fp32 class, and against the fp32 direct kernel it replaces."""
+    from medfusion_amd import blocks as BLK
+    from medfusion_amd import kernels as K
+    from medfusion_amd import lib as L
+    n, c, h, w, co, k = case
+    scale = torch.tensor([[1.0, 2.0 ** 12, 2.0 ** -9][i % 3] for i in range(n)]).view(n, 1, 1, 1)
+    x = (_rand(f"ix{case}", (n, c, h, w)) * scale).to(dev)
+    xp = K.pack_nchw_pairs(x, 32)
+    assert K.pairs_only(xp) and torch.equal(xp._mf_bound, x.abs().amax(dim=(1, 2, 3)))
+    ref = torch.zeros((n, h, w, 32), device=dev)
+    ref[..., :c] = K.nchw_to_nhwc(x)
+    assert torch.equal(xp._mf_split, K.split_f16x2(ref, xp._mf_bound))
+    conv = BLK.Conv(c, co, k, 1, R.monai_padding(k, 1)).to(dev)
+    S.synth_state_dict(conv, f"ic{case}.")
+    want = F.conv2d(x.cpu().double(), conv.weight.detach().cpu().double(), conv.bias.detach().cpu().double(), padding=conv.pad).float()
+    old = BLK.INPUT_CONV_ON_PAIRS
+    try:
+        BLK.INPUT_CONV_ON_PAIRS = True
+        y_new = conv(x, in_layout=L.LAYOUT_NCHW)
+        assert getattr(y_new, "_mf_split", None) is not None and getattr(y_new, "_mf_bound", None) is not None      # the pair form came with it
+        assert torch.equal(y_new._mf_split, K.split_f16x2(y_new, y_new._mf_bound))
+        BLK.INPUT_CONV_ON_PAIRS = False
+        conv._descs.clear()
+        y_old = conv(x, in_layout=L.LAYOUT_NCHW)
+    finally:
+        BLK.INPUT_CONV_ON_PAIRS = old
+    e_new, e_old = relerr_rows_local(K.nhwc_to_nchw(y_new), want), relerr_rows_local(K.nhwc_to_nchw(y_old), want)
+    assert e_new < 1e-6 and e_new < 3 * e_old + 2e-7, (case, e_new, e_old)
+
+
+def relerr_rows_local(a, b):
+    a, b = a.detach().cpu().double().reshape(a.shape[0], -1), b.detach().cpu().double().reshape(b.shape[0], -1)
+    return float(((a - b).abs().amax(1) / b.abs().amax(1)).max())
+
+
 FUSED_CASES = [
     # (N, H, W, C1, C2, Cout, k, G, tile, split-K, residual, emb, out_fp32)   residual: none | f32 (identity, bound known) | pairs (pairs-only) | slots (a conv_res output)
     (16, 32, 32, 256, 0, 256, 3, 32, 52, 1, "f32", True, True),       # the dominant launch of cfg2: 256 workgroups, 16 tiles per sample
