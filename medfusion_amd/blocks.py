@@ -105,7 +105,10 @@ class _Packed:
 
 
 PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"   # (A/B switch of the pairs-only apply output)
-INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "1") != "0"   # (A/B switch: the NCHW input convolution on the fp16-pair kernel)
+# the NCHW input convolution on the fp16-pair kernel (mf_pack_nchw_pairs_f32 + zero-padded weights): built, tested, and measured NOT faster on cfg2
+# (33.22 / 33.24 vs 33.23 / 33.32 images/s, two interleaved rounds: the 9-chunk matrix launch + the pack launch cost what the fp32 direct kernel
+# + the measuring / split passes cost) -- opt-in, MEDFUSION_INPUT_CONV_PAIRS=1
+INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "0") == "1"
 DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
