@@ -215,7 +215,9 @@ int mf_gn_apply_f32(const float* x, const float* stats, const float* gamma, cons
  * A fp16-pair tensor carries a per-sample power-of-two scale derived from an UPPER BOUND of |value| over the sample (fp16 stops at
  * 65504, an un-normalised residual stream does not): the pass derives the bound of its output from its inputs --
  *   bound[n] = (stats ? bconst : x_bound[n]) + res_bound[n] + emb_bound[n],  bconst >= max|act(gn(x) gamma + beta)| =
- *   max|gamma| sqrt(group size) + max|beta| -- scales sample n by 2^-(floor(log2 bound[n]) - 14) and publishes bound[n] in out_bound. */
+ *   max|gamma| sqrt(group size) + max|beta| -- scales sample n by 2^-(floor(log2 bound[n]) - 14) and publishes bound[n] in out_bound.
+ *   The bounds handed in must BE bounds: the from-partials passes no longer clamp to the fp16 range (round 4: 4 VALU instructions per element in
+ *   a VALU-bound pass) -- a value above its sample's bound by more than 2x overflows its pair to Inf instead of saturating at 65504 2^s. */
 int mf_gn_apply_split_f32(const float* x, const float* stats, const float* gamma, const float* beta, const float* residual,
                           const float* emb, int64_t emb_stride, float* out, void* out_split, const float* x_bound, const float* res_bound,
                           const float* emb_bound, float bconst, float* out_bound, int N, int HW, int C, int G, int act, void* stream);

@@ -372,6 +372,11 @@ def test_hipgraph_captured_step_equals_eager(dev, use_ddim, cond):
     eager = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), loop="eager", **kw)
     graph = pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), use_graph=True, **kw)
     assert torch.equal(eager, graph)
+    pipe.hoist_embeddings = False     # the embedding path evaluated INSIDE the loop (no table, no per-iteration gather): the same bits
+    try:
+        assert torch.equal(eager, pipe.sample(4, (8, 8, 8), noise=M.PhiloxDeviceNoise(77), loop="eager", **kw))
+    finally:
+        pipe.hoist_embeddings = True
     # the native command list of the loop body (iteration 1 recorded by the library, the rest re-issued from C): the same bits, and it is
     # what sample() does by default
     pipe.last_cmdlist_launches = 0
