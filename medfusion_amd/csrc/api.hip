@@ -68,18 +68,42 @@ static hipEvent_t get_event() {
   return e;
 }
 
-ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s) {
+static thread_local ProfScope* g_scope = nullptr;   // the innermost timing scope of the calling thread
+
+ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s), launches(0) {
   if (!g_prof) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfRec r{family, get_event(), get_event(), flops, bytes, exec_flops < 0 ? flops : exec_flops};
-  (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
+  g_scope = this;
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  (void)hipEventRecord(g_recs[idx].b, stream);
+  if (g_scope == this) g_scope = nullptr;
+  if (launches == 0) {   // a scope without a launch (an entry point that returned early): both events recorded here so that the query finds them
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_recs[idx].a, stream);
+    (void)hipEventRecord(g_recs[idx].b, stream);
+  }
+}
+
+bool prof_launch(const void* func, dim3 grid, dim3 block, void** argv, size_t lds, hipStream_t s) {
+  ProfScope* sc = g_scope;
+  if (sc == nullptr || sc->idx < 0) return false;
+  hipEvent_t a, b;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    a = g_recs[sc->idx].a;
+    b = g_recs[sc->idx].b;
+  }
+  if (sc->launches++ == 0) {
+    (void)hipExtLaunchKernel(func, grid, block, argv, lds, s, a, b, 0);
+    return true;
+  }
+  (void)hipLaunchKernel(func, grid, block, argv, lds, s);   // second, third ... launch of the scope: the stop event moves behind it
+  (void)hipEventRecord(b, s);
+  return true;
 }
 
 }  // namespace mf

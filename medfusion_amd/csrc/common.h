@@ -1,6 +1,7 @@
 // common.h -- shared host-side plumbing for libmedfusion_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -23,8 +24,14 @@ struct ProfScope {
   ~ProfScope();
   int idx;
   hipStream_t stream;
+  int launches;   // launches issued inside this scope so far
 };
 bool prof_on();
+// Timing of a scope (round 4): its FIRST launch goes out through hipExtLaunchKernel with the scope's two events as the dispatch's own start / stop
+// events -- the kernel's execution interval as the profiler sees it, no event packets in the queue between dependent kernels (two hipEventRecord
+// per launch inflated the conv family by ~4 % against rocprofv3).  A further launch in the same scope re-records the stop event behind itself.
+// -> true: `launch_impl` issued the kernel itself.
+bool prof_launch(const void* func, dim3 grid, dim3 block, void** argv, size_t lds, hipStream_t s);
 
 // ---- every kernel of the library is launched through MF_LAUNCH: an ordinary hipLaunchKernel -- and, while a command list records on the
 // calling thread (mf_cmdlist_begin), the same launch plus a copy of (kernel, geometry, kernarg bytes).  mf_cmdlist_replay re-issues the
@@ -43,6 +50,7 @@ inline void launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
     const size_t aligns[sizeof...(KArgs) + 1] = {alignof(std::decay_t<KArgs>)..., 0};
     cmdlist_add(cl, reinterpret_cast<const void*>(kernel), grid, block, lds, argv, sizes, aligns, (int)sizeof...(KArgs));
   }
+  if (prof_on() && prof_launch(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, s)) return;
   (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, lds, s);
 }
 template <typename... KArgs, typename... Args>
