@@ -355,6 +355,9 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes / n),   # operands read once + output written once (fp32 sizes), same average
                 "launches": int(n), "avg_launch_ms": round(ms / n, 5), "share_of_gpu_time": round(ms / total_ms, 4),
+                "launch_timing": "every launch's own start/stop HIP events (hipExtLaunchKernel: the dispatch's execution interval, what rocprofv3 --kernel-trace "
+                                 "reports; no event packets between dependent kernels -- until round 3 two hipEventRecord per launch inflated the conv family "
+                                 "by ~4 % against the profiler); kernel boundaries are therefore NOT in families_ms",
                 "families_ms": {k: round(v[0], 3) for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])},
                 "hbm_bound_passes": hbm}
     alts = []
