@@ -219,9 +219,9 @@ int dispatch_tile(int id, const mfc2::ConvP2& p, hipStream_t s, int terms, int m
 // split-K met inside the launch (conv_f16x2.h: ConvP2::tree) instead of slabs + reducer pass: a power-of-two split whose hand-off region
 // stays addressable with 32-bit offsets.  MF_CONV_TREE=0 keeps the reducer (A/B).
 // MF_CONV_TREE: 0 = slabs + reducer pass, 1 = in-launch hand-off through sc1 stores / sc1 loads, 2 = the same with release / acquire
-// fences around the pair counter, 3 = the counter first: only the first arriver of a pair stores its tile (round 4 experiment)
+// fences around the pair counter
 int tree_mode() {
-  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); const int v = e ? atoi(e) : 1; return v < 0 || v > 3 ? 1 : v; }();
+  static const int env = [] { const char* e = getenv("MF_CONV_TREE"); const int v = e ? atoi(e) : 1; return v < 0 || v > 2 ? 1 : v; }();
   return env;
 }
 bool tree_possible(const MfConvDesc* d, const Plan2& pl) {
@@ -351,7 +351,7 @@ static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of 
 int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {
   Plan2 pl;
   if (!d || !pair_precision(d->precision) || make_plan2(d, &pl) != MF_OK || !pl.ok || !tree_possible(d, pl)) return 0;
-  return 2 * cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * (pl.splitk - 1);   // the pairs' counters, then their `ready` words (MF_CONV_TREE=3)
+  return cdiv(pl.M, pl.t.BM) * (d->Cout / pl.t.BN) * (pl.splitk - 1);
 }
 
 // can this convolution apply the GroupNorm that follows it inside its own launch (conv_f16x2.h: FuseP): statistics from the epilogue of
