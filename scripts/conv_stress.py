@@ -42,6 +42,11 @@ CASES = [
     (16, 8, 8, 1024, 1024, 1024, 3, 51, 8),
     (16, 32, 32, 256, 256, 256, 3, 62, 2),      # the two halo-tile plans of the product path (conv_plan_table.inc, round 3): two-source 3x3
     (16, 16, 16, 512, 512, 512, 3, 62, 4),
+    (16, 16, 16, 512, 0, 512, 3, 34, 2),        # the 8-wave 128 x 128 tile on the split-K shapes of cfg2 (plan table, round 4 re-sweep)
+    (16, 8, 8, 1024, 0, 1024, 3, 34, 4),
+    (16, 8, 8, 1024, 512, 512, 3, 34, 8),
+    (16, 16, 16, 512, 256, 256, 3, 34, 4),
+    (16, 8, 8, 1024, 1024, 1024, 3, 62, 8),
 ]
 
 
