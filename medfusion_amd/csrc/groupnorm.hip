@@ -412,7 +412,8 @@ int mf_gn_apply_from_partials_pairs_f32(const float* x, const double* gn_partial
   MF_REQUIRE(per4 < (1L << 31), MF_EUNSUPPORTED, "gn_apply_from_partials: %ld float4 per sample", per4);
   // float4 per thread and round: as many as leave ~4 workgroups per CU over the whole launch (small tensors: more, shorter workgroups)
   const long total_blocks = ((long)N * per4 + 255) / 256;
-  const int U = total_blocks >= 4 * 1024 ? 4 : total_blocks >= 2 * 1024 ? 2 : 1;
+  static const int force_u = [] { const char* e = getenv("MF_GN_U"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();   // (A/B knob)
+  const int U = force_u ? force_u : total_blocks >= 4 * 1024 ? 4 : total_blocks >= 2 * 1024 ? 2 : 1;
   long bps = (per4 + 256 * U - 1) / (256 * U);
   // workgroups per CU over the whole launch: every workgroup reduces the sample's records before it starts (~3 us), so FEWER, fatter ones
   // amortise it -- MF_GN_BLOCKS_PER_CU (read once; A/B knob)
