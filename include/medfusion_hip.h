@@ -129,6 +129,9 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
                     const float* x2_bound, float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync,
                     double* gn_partial, int G, const MfConvDesc* d, void* stream);
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
+/* A run-time override of the planner's choice for the shape of `d` (ABI 220; tile = 0 removes it): consulted before the built-in table when the
+ * descriptor carries no hints.  For tuning inside the real pipeline (scripts/plan_tune.py) -- the table is what ships. */
+int mf_conv2d_plan_override(const MfConvDesc* d, int tile, int splitk);
 
 /* Convolution + GroupNorm + Swish + residual + embedding in ONE launch (ABI 220; BasicBlock.forward / BasicResBlock.forward,
  * conv_blocks.py:185-191,236-240, with the `x += emb` of :360-363): the fp16-pair convolution whose workgroups keep their final tile in

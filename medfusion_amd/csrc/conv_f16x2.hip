@@ -2,6 +2,8 @@
 // Replaces torch.nn.Conv2d.forward at conv_blocks.py:185,238,66,123-125 and unet2.py:259 (include/medfusion_hip.h has the call-site map).
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "gn_partial.h"
 #include "conv_plan.h"
 #include "conv_f16x2.h"
@@ -57,6 +59,11 @@ const PlanEntry kPlanTable[] = {
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
 };
 
+// plan overrides set at run time (mf_conv2d_plan_override: the in-pipeline tuner scripts/plan_tune.py tries candidate plans per shape without a
+// rebuild); consulted before the static table
+std::vector<PlanEntry> g_plan_overrides;
+std::mutex g_plan_mu;
+
 struct Plan2 {
   bool ok;
   Tile2 t;
@@ -98,7 +105,17 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
     if (!halo_fits(d, *c)) { pl->ok = false; return MF_OK; }
   } else {
-    for (const auto& e : kPlanTable) {
+    {
+      std::lock_guard<std::mutex> lk(g_plan_mu);
+      for (const auto& e : g_plan_overrides) {
+        if (e.N == d->N && e.H == d->Hin && e.W == d->Win && e.Cin == Cin && e.Cout == d->Cout && e.k == d->KH && e.stride == d->stride && e.ups == d->upsample) {
+          for (const auto& k : kTiles2) if (k.id == e.tile && valid(k)) c = &k;
+          if (c && sk_ok(e.sk)) sk = e.sk;
+          break;
+        }
+      }
+    }
+    if (c == nullptr) for (const auto& e : kPlanTable) {
       if (e.N == d->N && e.H == d->Hin && e.W == d->Win && e.Cin == Cin && e.Cout == d->Cout && e.k == d->KH && e.stride == d->stride &&
           e.ups == d->upsample) {
         for (const auto& k : kTiles2) if (k.id == e.tile && valid(k)) c = &k;
@@ -346,6 +363,21 @@ static int host_scale_exp(float bound) {  // the host-side twin of scale_exp_of 
   memcpy(&u, &bound, 4);
   const int s = (int)((u >> 23) & 0xffu) - 127 - 14;
   return s < -100 ? -100 : (s > 100 ? 100 : s);
+}
+
+int mf_conv2d_plan_override(const MfConvDesc* d, int tile, int splitk) {
+  MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "plan_override: a MF_CONV_FP32_F16X2 / MF_CONV_F16 descriptor");
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  const int Cin = d->C1 + d->C2;
+  for (size_t i = 0; i < g_plan_overrides.size(); ++i) {
+    const PlanEntry& e = g_plan_overrides[i];
+    if (e.N == d->N && e.H == d->Hin && e.W == d->Win && e.Cin == Cin && e.Cout == d->Cout && e.k == d->KH && e.stride == d->stride && e.ups == d->upsample) {
+      g_plan_overrides.erase(g_plan_overrides.begin() + i);
+      break;
+    }
+  }
+  if (tile > 0 && splitk > 0) g_plan_overrides.push_back(PlanEntry{d->N, d->Hin, d->Win, Cin, d->Cout, d->KH, d->stride, d->upsample, tile, splitk});
+  return MF_OK;
 }
 
 int mf_conv2d_f16x2_sync_words(const MfConvDesc* d) {

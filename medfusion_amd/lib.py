@@ -68,6 +68,7 @@ _SIGS = {
     "mf_maxabs_rows_f32": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
     "mf_bound_finalize_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),
     "mf_conv2d_f16x2_bound_slots": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_conv2d_plan_override": (_I, [C.POINTER(MfConvDesc), _I, _I]),
     "mf_conv2d_plan_query": (_I, [C.POINTER(MfConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mf_gn_apply_split_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I64, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _I, _I, _I, _I, _I, c_fp]),
     "mf_gn_apply_from_partials_f32": (_I, [c_fp, c_fp, _I, _F, c_fp, c_fp, c_fp, c_fp, _I64, c_fp, c_fp, c_fp, c_fp, _I, c_fp, _F, c_fp, _I, _I, _I, _I, _I, c_fp]),
