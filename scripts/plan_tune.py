@@ -19,11 +19,13 @@ ap.add_argument("sweep")
 ap.add_argument("--top", type=int, default=3)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--latent", type=int, default=32, help="latent size (64: the 512-px workload)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 pipe = P.build_published_pipeline(dev, None)
 lib = L.load()
-shapes = {s[0]: s for s in unet_shapes(a.batch)}
+f_ = a.latent // 32
+shapes = {s[0]: (s[0], s[1], s[2] * f_, s[3] * f_, *s[4:]) for s in unet_shapes(a.batch)}
 cands = {}
 for ln in Path(a.sweep).read_text().splitlines():
     parts = ln.split("|")
@@ -50,13 +52,13 @@ def clear_caches():
 
 def run(nsteps, seed):
     for k in range(nsteps):
-        pipe.sample(a.batch, (8, 32, 32), steps=150, use_ddim=True, noise=M.PhiloxDeviceNoise(seed + k), decode=False)
+        pipe.sample(a.batch, (8, a.latent, a.latent), steps=150, use_ddim=True, noise=M.PhiloxDeviceNoise(seed + k), decode=False)
     torch.cuda.synchronize()
 
 
 def timed():
     clear_caches()
-    pipe.sample(a.batch, (8, 32, 32), steps=12, use_ddim=True, noise=M.PhiloxDeviceNoise(1), decode=False)   # plans, workspaces, command list
+    pipe.sample(a.batch, (8, a.latent, a.latent), steps=12, use_ddim=True, noise=M.PhiloxDeviceNoise(1), decode=False)   # plans, workspaces, command list
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.reps, 100)
