@@ -290,3 +290,27 @@ def test_default_noise_is_stateful_and_reseedable():
     e = M.PhiloxDeviceNoise(5)
     e.begin(2, dev)
     assert e._seed == 5
+
+
+def _forced_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MEDFUSION_FORCE_COLLECTIVE="1")
+    r, _, w = D.init_from_env(backend="gloo")
+    assert (r, w) == (0, 1) and dist.is_initialized()       # a process group although the world is 1
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda bufs, src, *a, **k: (calls.append(len(bufs)), real(bufs, src, *a, **k))[1]
+    noise = M.HostNoise(lambda shape: S.PhiloxNoise(11)(torch.empty(tuple(shape))))
+    full = D.sample_sharded(_FakePipe(), 5, (2, 4, 4), condition=torch.arange(5) % 3, noise=noise)
+    assert calls == [1]                                       # the gather went through the collective, not the world-1 shortcut
+    torch.save(full, Path(out_dir) / "forced.pt")
+    dist.destroy_process_group()
+
+
+def test_forced_collective_on_a_one_rank_group(tmp_path):
+    """MEDFUSION_FORCE_COLLECTIVE=1 (dist.init_from_env / gather_images): the 1-rank group runs the same all-gather the N-rank job runs --
+    the switch tests/test_multiproc_gpu.py::test_rccl_world1_device_allgather uses on the single-GPU box, here over gloo"""
+    mp.spawn(_forced_worker, args=(29950 + os.getpid() % 40, str(tmp_path)), nprocs=1, join=True)
+    noise = M.HostNoise(lambda shape: S.PhiloxNoise(11)(torch.empty(tuple(shape))))
+    want = _FakePipe().sample(5, (2, 4, 4), condition=torch.arange(5) % 3, noise=noise, shard=(0, 1))
+    assert torch.equal(torch.load(tmp_path / "forced.pt"), want)
+    assert os.environ.get("MEDFUSION_FORCE_COLLECTIVE") is None   # the child's environment did not leak

@@ -143,3 +143,44 @@ def test_pinned_plan_equals_the_planners_choice():
         assert need == lib.mf_conv2d_workspace_bytes(C.byref(free)) and slots == lib.mf_conv2d_f16x2_bound_slots(C.byref(free))
         assert words == lib.mf_conv2d_f16x2_sync_words(C.byref(free))
         assert lib.mf_conv2d_gn_parts(C.byref(d), 32) == lib.mf_conv2d_gn_parts(C.byref(free), 32)
+
+
+def test_run_time_plan_override_round_trip():
+    """mf_conv2d_plan_override (ABI 220, scripts/plan_tune.py): consulted before the built-in table for a descriptor without hints; tile = 0
+    removes it; an invalid tile or split leaves the table's plan; hints in the descriptor still win."""
+    lib = L.load()
+    d = _d(16, 16, 16, 512, 0, 512, prec=5)
+    table = K.conv_plan(d)
+    other = (52, 4) if table != (52, 4) else (34, 2)
+    try:
+        assert lib.mf_conv2d_plan_override(C.byref(d), *other) == 0
+        assert K.conv_plan(d) == other
+        assert lib.mf_conv2d_workspace_bytes(C.byref(d)) >= 2 * (other[1] - 1) * 16 * 16 * 16 * 512 * 4  # the workspace follows the plan in force
+        assert K.conv_plan(_d(16, 16, 16, 512, 0, 512, prec=5, tile=table[0], sk=table[1])) == table     # hints win over the override
+        untouched = _d(16, 32, 32, 256, 0, 256, prec=5)
+        before = K.conv_plan(untouched)
+        assert lib.mf_conv2d_plan_override(C.byref(d), 999, 2) == 0                                      # unknown tile: ignored when planning
+        assert K.conv_plan(d) == table and K.conv_plan(untouched) == before
+    finally:
+        assert lib.mf_conv2d_plan_override(C.byref(d), 0, 0) == 0
+    assert K.conv_plan(d) == table
+    assert lib.mf_conv2d_plan_override(None, 34, 2) != 0
+
+
+def test_every_entry_of_the_plan_table_is_taken_as_written():
+    """conv_plan_table.inc is hand-/sweep-written: an entry whose tile does not fit its shape (halo, Cout % BN, chain length) would be skipped
+    silently by make_plan2 and the cost model's choice used instead -- the sweep's gain lost without a failing test.  Every entry must come
+    back from mf_conv2d_plan_query exactly."""
+    import re
+    from medfusion_amd import build as B
+    rows = re.findall(r"\{\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*\}",
+                      (B.CSRC / "conv_plan_table.inc").read_text())
+    assert len(rows) >= 100
+    lib = L.load()
+    bad = []
+    for r in rows:
+        n, h, w, cin, co, k, stride, ups, tile, sk = map(int, r)
+        d = K.make_conv_desc(n, h, w, cin, 0, co, k, stride, 1 if k == 3 else 0, ups, L.LAYOUT_NHWC, L.LAYOUT_NHWC, precision=5)
+        if lib.mf_conv2d_f16x2_ok(C.byref(d)) != 1 or K.conv_plan(d) != (tile, sk):
+            bad.append((r, K.conv_plan(d)))
+    assert not bad, bad
