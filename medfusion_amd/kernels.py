@@ -132,13 +132,13 @@ class Rendezvous:
         if not cls.used.get(device.index):
             return False
         cls.used[device.index] = False
+        torch.cuda.synchronize(device)   # (every stream of the device: .item() below would wait for the current one only)
         bad = False
-        for (di, _), buf in cls._bufs.items():
+        for (di, _), buf in list(cls._bufs.items()):
             if di == device.index and int(buf[0].item()) != 0:
                 bad = True
         if bad:
-            torch.cuda.synchronize(device)
-            for (di, _), buf in cls._bufs.items():
+            for (di, _), buf in list(cls._bufs.items()):
                 if di == device.index:
                     buf.zero_()
         return bad
@@ -148,7 +148,7 @@ class Rendezvous:
 # sample finish too far apart (deep in-launch split-K trees at 8 x 8) for the wait to beat a separate apply launch (scripts/conv_timeline.py
 # --fused, profiles/r04_conv_timeline_fused.txt).  The C-ABI query (mf_conv2d_f16x2_fuse_words) answers capability only.
 FUSE_MIN_HW = int(os.environ.get("MEDFUSION_FUSE_MIN_HW", "256"))
-_fused_depth = [0]
+_fused = __import__("threading").local()   # .depth: nesting of with_fused_fallback on THIS thread (two threads may drive two streams)
 
 
 def with_fused_fallback(device, fn, rewind=None):
@@ -156,13 +156,13 @@ def with_fused_fallback(device, fn, rewind=None):
     timed out waiting for its sample (Rendezvous: only when another process's waiting workgroups fill the device), switch that form off for
     the process, call `rewind()` (restore whatever fn consumed: noise counters) and run fn() again on the two-launch form.  Nested calls
     (the decode inside a sampling loop) leave the check to the outermost one: a failure anywhere invalidates everything after it."""
-    if _fused_depth[0] > 0 or Rendezvous.disabled or torch.cuda.is_current_stream_capturing():
+    if getattr(_fused, "depth", 0) > 0 or Rendezvous.disabled or torch.cuda.is_current_stream_capturing():
         return fn()
-    _fused_depth[0] += 1
+    _fused.depth = 1
     try:
         out = fn()
     finally:
-        _fused_depth[0] -= 1
+        _fused.depth = 0
     if Rendezvous.failed(device):
         import warnings
         Rendezvous.disabled = True
