@@ -201,7 +201,10 @@ def pmc_traffic(match):
     profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950)."""
     try:
         pj = json.load(open(ROOT / "profiles" / "pmc_bench_traffic.json"))
-        cand = [e for e in pj["kernels"] if all(m in e["kernel"] for m in match)]
+        # every instantiation of the arithmetic's matrix kernels: the 9-copy kernel, the halo kernel and the grouped launches (two convolutions
+        # in one grid); match[1:] narrows to the single-term instantiations where the arithmetic has its own
+        names = ("conv_f16x2_kernel<", "conv_halo_kernel<", "conv_group_kernel<")
+        cand = [e for e in pj["kernels"] if any(nm in e["kernel"] for nm in names) and all(m in e["kernel"] for m in match[1:])]
         if cand:
             top = max(cand, key=lambda e: e.get("launches", 0))
             n = sum(e["launches"] for e in cand)

@@ -133,6 +133,24 @@ int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk)
  * descriptor carries no hints.  For tuning inside the real pipeline (scripts/plan_tune.py) -- the table is what ships. */
 int mf_conv2d_plan_override(const MfConvDesc* d, int tile, int splitk);
 
+/* TWO independent fp16-pair convolutions in ONE launch (ABI 220; BasicResBlock.forward, conv_blocks.py:194-240: `conv_res(x)` (:238) and the 3x3
+ * convolution of the block (:185) read the same x and neither reads the other's result).  The grid is a's workgroups followed by b's: a -- the
+ * large one -- fills the device as it does alone, b's workgroups take the CUs a's workgroups leave; no kernel boundary between the two, b's ramp
+ * under a's drain.  Every workgroup runs the unchanged code of its own convolution, so both results are bit-identical to two mf_conv2d_f16x2
+ * calls with the same arguments (each call struct holds exactly those arguments).  mf_conv2d_f16x2_group_ok(a, Ga, b, Gb): can these two plans
+ * share a launch (Ga / Gb: groups of the GroupNorm statistics asked of a / b, 0 = none) -- both MF_CONV_FP32_F16X2, both finishing inside their
+ * launch (no slab + reducer pass), equal workgroup sizes, a tile pair that is instantiated (the pairs cfg2's channel-changing ResBlocks use;
+ * descriptor hints choose b's tile).  When both meet their split-K slices inside the launch, their workspaces and sync arrays must not overlap. */
+typedef struct MfConvF16x2Call {
+  const void* x1s; const void* x2s; const void* ws; const float* bias; float* y;
+  const float* x1_bound; const float* x2_bound; float w_bound; float* y_bound;
+  void* workspace; size_t workspace_bytes; uint32_t* sync;
+  double* gn_partial; int G;
+  const MfConvDesc* d;
+} MfConvF16x2Call;
+int mf_conv2d_f16x2_group_ok(const MfConvDesc* a, int Ga, const MfConvDesc* b, int Gb);
+int mf_conv2d_f16x2_group(const MfConvF16x2Call* a, const MfConvF16x2Call* b, void* stream);
+
 /* Convolution + GroupNorm + Swish + residual + embedding in ONE launch (ABI 220; BasicBlock.forward / BasicResBlock.forward,
  * conv_blocks.py:185-191,236-240, with the `x += emb` of :360-363): the fp16-pair convolution whose workgroups keep their final tile in
  * registers, publish the tile's partial GroupNorm sums (gn_partial, as in mf_conv2d_f16x2), meet the other tiles of their SAMPLE at a

@@ -109,6 +109,9 @@ PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"  
 # (33.22 / 33.24 vs 33.23 / 33.32 images/s, two interleaved rounds: the 9-chunk matrix launch + the pack launch cost what the fp32 direct kernel
 # + the measuring / split passes cost) -- opt-in, MEDFUSION_INPUT_CONV_PAIRS=1
 INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "0") == "1"
+# conv_res in the launch of the block's 3x3 (mf_conv2d_f16x2_group; conv_f16x2_group.h).  Bit-identical to the two launches; UNMEASURED at the end
+# of round 4 (built after the round's GPU budget was spent) -- therefore opt-in, MEDFUSION_GROUPED_CONV_RES=1, until an A/B on the device decides
+GROUPED_CONV_RES = os.environ.get("MEDFUSION_GROUPED_CONV_RES", "0") == "1"
 DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
@@ -380,6 +383,7 @@ class BasicResBlock(nn.Module):
         self.basic_block = BasicBlock(spatial_dims, in_channels, out_channels, kernel_size, stride, norm_name, act_name, dropout, zero_conv)
         self.conv_res = Conv(in_channels, out_channels, 1, stride, monai_padding(1, stride)) if in_channels != out_channels else nn.Identity()
         self._pairs_ok = {}
+        self._group = {}
 
     def forward(self, x: Act, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_fp32=True):
         """out_fp32=False: the caller promises that the block's output is read by fp16-pair convolutions and residual adds only"""
@@ -387,8 +391,55 @@ class BasicResBlock(nn.Module):
             if isinstance(x, (tuple, list)) or in_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("identity residual needs a single NHWC input")
             return self.basic_block(x, residual=x, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
+        if GROUPED_CONV_RES and CONV_PRECISION == 5 and in_layout == L.LAYOUT_NHWC and hasattr(self.basic_block, "norm") and K.Rendezvous.disabled:
+            g = self._grouped(x)
+            if g is not None:
+                # conv_res and the block's 3x3 read the same x and not each other: ONE launch (mf_conv2d_f16x2_group) -- the 3x3's workgroups
+                # first, the 1x1's on the CUs they leave; bit-identical to the two launches below
+                x1, x2 = _split(x)
+                bb, nm = self.basic_block, self.basic_block.norm
+                (y, partial), res = K.conv2d_f16x2_group(
+                    x1, x2,
+                    dict(w_split=bb.conv._packed.get_f16x2(bb.conv.weight), bias=bb.conv.bias, d=g[0], gn_groups=nm.num_groups, gn_parts=g[1], pinned=g[2]),
+                    dict(w_split=self.conv_res._packed.get_f16x2(self.conv_res.weight), bias=self.conv_res.bias, d=g[3], pinned=g[4]))
+                return bb.finish((y, K.GnPartials(partial, g[1], nm.eps)), res, emb, emb_stride, out_fp32)
         res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
         return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
+
+    def _grouped(self, x):
+        """(descriptor, GroupNorm parts, pinned) of the 3x3 + (descriptor, pinned) of conv_res when the two can share a launch for this input
+        shape, else None; cached per shape.  conv_res keeps the planner's tile when its workgroup size equals the 3x3's, otherwise the first
+        of the guest tiles of that size the pair is instantiated for (descriptor hints)."""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        key = (n, h, w, c1, c2)
+        if key in self._group:
+            return self._group[key]
+        ent = None
+        c3, cr, nm = self.basic_block.conv, self.conv_res, self.basic_block.norm
+        G = nm.num_groups
+        if c1 + c2 == c3.in_ch and not c3.upsample and G <= 256:
+            da = K.make_conv_desc(n, h, w, c1, c2, c3.out_ch, c3.k, c3.stride, c3.pad, 0, precision=5)
+            if K.conv_f16x2_ok(da):
+                pa = K.pin_conv_plan(da)
+                parts = K.conv_gn_parts(da, G)
+                # guest tiles of the 8-wave hosts: the one whose grid is closest to one workgroup per CU first (profiles/r04_conv_sweep_planner_vs_best.txt)
+                m = n * ((h + 2 * cr.pad - cr.k) // cr.stride + 1) * ((w + 2 * cr.pad - cr.k) // cr.stride + 1)
+                t36, t37 = -(-m // 128) * (cr.out_ch // 64), -(-m // 64) * max(cr.out_ch // 256, 1)
+                wide = (36, 37) if abs(t36 - 256) <= abs(t37 - 256) or cr.out_ch % 256 else (37, 36)
+                for tile in (0, *wide, 53):
+                    if tile == 37 and cr.out_ch % 256:
+                        continue
+                    db = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, tile_hint=tile, precision=5)
+                    if not K.conv_f16x2_ok(db):
+                        continue
+                    pb = K.pin_conv_plan(db)
+                    if parts > 0 and pb[1] > 0 and K.conv_group_ok(da, G, db, 0):
+                        ent = (da, parts, pa, db, pb)
+                        break
+        self._group[key] = ent
+        return ent
 
     def reads_pairs_only(self, n: int, h: int, w: int) -> bool:
         """can this block take an [n, h, w, Cin] input that exists as fp16 pairs only?  Its convolutions must be on the fp16-pair kernel FOR

@@ -8,6 +8,7 @@
 #include "conv_plan.h"
 #include "conv_f16x2.h"
 #include "conv_f16x2_halo.h"
+#include "conv_f16x2_group.h"
 
 using namespace mf;
 
@@ -229,6 +230,37 @@ int dispatch_tile(int id, const mfc2::ConvP2& p, hipStream_t s, int terms, int m
     case 62: return launch_halo<256, 128, 4, 2, 7>(p, s, terms, mode);
     case 63: return launch_halo<128, 128, 2, 4, 4>(p, s, terms, mode);
     case 64: return launch_halo<128, 128, 2, 4, 5>(p, s, terms, mode);
+    default: return -1;
+  }
+}
+
+// ---- two convolutions in one launch (conv_f16x2_group.h): the tile pairs the plans of cfg2's channel-changing ResBlocks need (3x3 host
+// tile, 1x1 guest tile), three-term arithmetic only.  mode 0: launch; mode 2: is the pair instantiated (1 / -1)
+template <class A, class B>
+int launch_group(const mfc2::ConvP2& pa, const mfc2::ConvP2& pb, hipStream_t s, int mode) {
+  if (mode == 2) return 1;
+  constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
+  static DeviceOnce once;
+  const void* fn = reinterpret_cast<const void*>(&mfc2::conv_group_kernel<A, B, 3>);
+  if (first_use_on_device(once)) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int na = pa.tiles_m * pa.tiles_n * pa.splitk, nb = pb.tiles_m * pb.tiles_n * pb.splitk;
+  MF_LAUNCH((mfc2::conv_group_kernel<A, B, 3>), dim3(na + nb), dim3(A::threads), lds, s, pa, pb, na);
+  return check_launch("conv_f16x2_group");
+}
+int dispatch_group(int ida, int idb, const mfc2::ConvP2& pa, const mfc2::ConvP2& pb, hipStream_t s, int mode) {
+  using T34 = mfc2::PlainTile<128, 128, 4, 2, 3>;
+  using T36 = mfc2::PlainTile<128, 64, 4, 2, 3>;
+  using T37 = mfc2::PlainTile<64, 256, 1, 8, 3>;
+  using T53 = mfc2::PlainTile<64, 128, 2, 2, 3>;
+  using T54 = mfc2::PlainTile<128, 64, 2, 2, 3>;
+  using T62 = mfc2::HaloTile<256, 128, 4, 2, 7>;
+  switch (ida * 100 + idb) {
+    case 5353: return launch_group<T53, T53>(pa, pb, s, mode);
+    case 5453: return launch_group<T54, T53>(pa, pb, s, mode);
+    case 3436: return launch_group<T34, T36>(pa, pb, s, mode);
+    case 3437: return launch_group<T34, T37>(pa, pb, s, mode);
+    case 6236: return launch_group<T62, T36>(pa, pb, s, mode);
+    case 6237: return launch_group<T62, T37>(pa, pb, s, mode);
     default: return -1;
   }
 }
@@ -455,11 +487,14 @@ int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, c
   return conv_f16x2_impl(x1s, x2s, ws, bias, nullptr, x1_bound, x2_bound, w_bound, nullptr, workspace, workspace_bytes, sync, gn_partial, G, f, d, stream);
 }
 
-static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
-                           float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
-                           const MfGnFuse* fz, const MfConvDesc* d, void* stream, const PairsOut* po) {
+// everything of a launch but the launch: checks, plan, kernel parameters.  (mf_conv2d_f16x2_group prepares two and launches once.)
+struct Prep { mfc2::ConvP2 p; Plan2 pl; bool tree; double flops, bytes; int terms; };
+static int conv_f16x2_prepare(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
+                              float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                              const MfGnFuse* fz, const MfConvDesc* d, const PairsOut* po, Prep* out) {
   MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2 (or the opt-in MF_CONV_F16)");
-  Plan2 pl;
+  Plan2& pl = out->pl;
+  mfc2::ConvP2& p = out->p;
   int rc = make_plan2(d, &pl);
   if (rc) return rc;
   MF_REQUIRE(pl.ok, MF_EUNSUPPORTED, "conv(f16x2): this shape/layout is not on the fp16-pair path (ask mf_conv2d_f16x2_ok)");
@@ -468,8 +503,6 @@ static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, con
   MF_REQUIRE(!gn_partial || gn_parts2(d, pl, G) > 0, MF_EUNSUPPORTED, "conv(f16x2): cannot emit GroupNorm partials (mf_conv2d_gn_parts == 0)");
   MF_REQUIRE(!y_bound || (!gn_partial && bound_slots2(d, pl, false) > 0), MF_EUNSUPPORTED,
              "conv(f16x2): cannot measure the output bound of this plan (mf_conv2d_f16x2_bound_slots == 0, or GroupNorm statistics requested)");
-  hipStream_t s = (hipStream_t)stream;
-  mfc2::ConvP2 p;
   p.x1 = x1s; p.x2 = x2s; p.w = ws; p.bias = bias; p.y = y;
   p.bound1 = x1_bound; p.bound2 = x2_bound; p.wexp = host_scale_exp(w_bound); p.out_bound = y_bound; p.bound_slots = y_bound ? bound_slots2(d, pl, false) : 0;
   p.N = d->N; p.Hin = d->Hin; p.Win = d->Win; p.C1 = d->C1; p.C2 = d->C2; p.Cin = d->C1 + d->C2; p.Cout = d->Cout;
@@ -516,11 +549,26 @@ static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, con
     p.y = reinterpret_cast<float*>(workspace);
     p.out_bound = nullptr;   // the reducer measures
   }
-  const double flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
-  const double bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
+  out->tree = tree;
+  out->flops = 2.0 * pl.M * (double)d->Cout * (d->upsample == 2 ? 9.0 * (d->C1 + d->C2) : (double)pl.K);
+  out->bytes = 4.0 * ((double)d->N * d->Hin * d->Win * p.Cin + (double)d->Cout * pl.K + (double)pl.M * d->Cout);
+  out->terms = d->precision == MF_CONV_F16 ? 1 : 3;
+  return MF_OK;
+}
+
+static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
+                           float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
+                           const MfGnFuse* fz, const MfConvDesc* d, void* stream, const PairsOut* po) {
+  Prep q;
+  int rc = conv_f16x2_prepare(x1s, x2s, ws, bias, y, x1_bound, x2_bound, w_bound, y_bound, workspace, workspace_bytes, sync, gn_partial, G, fz, d, po, &q);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const Plan2& pl = q.pl;
+  const mfc2::ConvP2& p = q.p;
+  const bool tree = q.tree;
   {
-    const int terms = d->precision == MF_CONV_F16 ? 1 : 3;
-    ProfScope ps(fz ? MF_FAM_CONV_GN_FUSED : MF_FAM_CONV_IGEMM, s, flops, bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
+    const int terms = q.terms;
+    ProfScope ps(fz ? MF_FAM_CONV_GN_FUSED : MF_FAM_CONV_IGEMM, s, q.flops, q.bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
     rc = dispatch_tile(pl.t.id, p, s, terms, 0);
     if (rc == -1) { set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL; }
   }
@@ -543,6 +591,54 @@ static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, con
     return check_launch("splitk_reduce");
   }
   return MF_OK;
+}
+
+/* ------------------------------------------------------------------ two independent convolutions in one launch (conv_f16x2_group.h) */
+// does the plan finish inside its launch (no slab + reducer pass behind it), given the GroupNorm statistics asked of it (G = 0: none)?
+static bool single_launch(const MfConvDesc* d, const Plan2& pl, int G) {
+  if (pl.splitk == 1) return G == 0 || gn_parts2(d, pl, G) > 0;
+  return tree_possible(d, pl) && (G == 0 || epilogue_stats_ok(d, pl, G));
+}
+
+int mf_conv2d_f16x2_group_ok(const MfConvDesc* a, int Ga, const MfConvDesc* b, int Gb) {
+  static const int off = [] { const char* e = getenv("MF_CONV_GROUP"); return e && atoi(e) == 0 ? 1 : 0; }();   // MF_CONV_GROUP=0: never (A/B)
+  if (off || !a || !b || a->precision != MF_CONV_FP32_F16X2 || b->precision != MF_CONV_FP32_F16X2) return 0;
+  Plan2 pa, pb;
+  if (make_plan2(a, &pa) != MF_OK || make_plan2(b, &pb) != MF_OK || !pa.ok || !pb.ok) return 0;
+  if (!single_launch(a, pa, Ga) || !single_launch(b, pb, Gb)) return 0;
+  mfc2::ConvP2 dummy{};
+  return dispatch_group(pa.t.id, pb.t.id, dummy, dummy, nullptr, 2) == 1 ? 1 : 0;
+}
+
+int mf_conv2d_f16x2_group(const MfConvF16x2Call* a, const MfConvF16x2Call* b, void* stream) {
+  MF_REQUIRE(a && b && a->d && b->d && a->y && b->y, MF_EINVAL, "conv_group: two calls with descriptors and outputs");
+  const int Ga = a->gn_partial ? a->G : 0, Gb = b->gn_partial ? b->G : 0;
+  MF_REQUIRE(mf_conv2d_f16x2_group_ok(a->d, Ga, b->d, Gb), MF_EUNSUPPORTED,
+             "conv_group: these two plans cannot share a launch (mf_conv2d_f16x2_group_ok == 0: a reducer pass behind one of them, workgroup sizes "
+             "that differ, or a tile pair that is not instantiated)");
+  Prep qa, qb;
+  int rc = conv_f16x2_prepare(a->x1s, a->x2s, a->ws, a->bias, a->y, a->x1_bound, a->x2_bound, a->w_bound, a->y_bound, a->workspace, a->workspace_bytes,
+                              a->sync, a->gn_partial, a->G, nullptr, a->d, nullptr, &qa);
+  if (rc) return rc;
+  rc = conv_f16x2_prepare(b->x1s, b->x2s, b->ws, b->bias, b->y, b->x1_bound, b->x2_bound, b->w_bound, b->y_bound, b->workspace, b->workspace_bytes,
+                          b->sync, b->gn_partial, b->G, nullptr, b->d, nullptr, &qb);
+  if (rc) return rc;
+  MF_REQUIRE((qa.pl.splitk == 1 || qa.tree) && (qb.pl.splitk == 1 || qb.tree), MF_EUNSUPPORTED, "conv_group: a plan needs its reducer pass");
+  if (qa.tree && qb.tree) {   // both meet their split-K slices inside the launch, at the same time: hand-off regions and counters must be their own
+    const char *wa = (const char*)a->workspace, *wb = (const char*)b->workspace;
+    const size_t na = tree_handoff_bytes(a->d, qa.pl), nb = tree_handoff_bytes(b->d, qb.pl);
+    MF_REQUIRE(wa + na <= wb || wb + nb <= wa, MF_EINVAL, "conv_group: the two workspaces overlap");
+    const uint32_t *sa = a->sync, *sb = b->sync;
+    const long ca = mf_conv2d_f16x2_sync_words(a->d), cb = mf_conv2d_f16x2_sync_words(b->d);
+    MF_REQUIRE(sa + ca <= sb || sb + cb <= sa, MF_EINVAL, "conv_group: the two sync arrays overlap");
+  }
+  MF_REQUIRE(a->y != b->y, MF_EINVAL, "conv_group: one output for two convolutions");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(MF_FAM_CONV_IGEMM, s, qa.flops + qb.flops, qa.bytes + qb.bytes,
+               2.0 * 3.0 * (qa.pl.M * (double)a->d->Cout * qa.pl.K + qb.pl.M * (double)b->d->Cout * qb.pl.K));
+  rc = dispatch_group(qa.pl.t.id, qb.pl.t.id, qa.p, qb.p, s, 0);
+  if (rc == -1) { set_error("conv_group: no tile pair (%d, %d)", qa.pl.t.id, qb.pl.t.id); rc = MF_EINVAL; }
+  return rc;
 }
 
 }  // extern "C"

@@ -405,6 +405,46 @@ def conv2d_f16x2(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor], d: L.M
     return (out, partial) if gn_groups else out
 
 
+def conv_group_ok(da: L.MfConvDesc, Ga: int, db: L.MfConvDesc, Gb: int) -> bool:
+    """can the two fp16-pair convolutions share one launch (mf_conv2d_f16x2_group_ok)?"""
+    return bool(L.load().mf_conv2d_f16x2_group_ok(C.byref(da), Ga, C.byref(db), Gb))
+
+
+def conv2d_f16x2_group(x1: torch.Tensor, x2: Optional[torch.Tensor], a, b):
+    """TWO independent fp16-pair convolutions of the same input (x1 | x2) in ONE launch (mf_conv2d_f16x2_group): a = the large one, followed by a
+    GroupNorm -- dict(w_split, bias, d, gn_groups, gn_parts, pinned) -> (y, partial records) --, b = the small one whose output is measured --
+    dict(w_split, bias, d, pinned) -> y with its bound slots attached.  Bit for bit what conv2d_f16x2(.., gn_groups=..) and
+    conv2d_f16x2(.., measure_out=True) return."""
+    _gpu(x1, x2, a["w_split"][0], b["w_split"][0], a["bias"], b["bias"])
+    lib = L.load()
+    dev = x1.device
+    x1s, b1 = split_of(x1), bound_of(x1)
+    x2s, b2 = (split_of(x2), bound_of(x2)) if x2 is not None else (None, None)
+    da, db = a["d"], b["d"]
+    need_a, _, words_a = a["pinned"]
+    need_b, slots_b, words_b = b["pinned"]
+    off_b = (need_a + 255) & ~255                      # b's hand-off region behind a's, its counters behind a's
+    ws = Workspace.get(off_b + need_b, dev) if (need_a or need_b) else None
+    sync = SyncWords.get(words_a + words_b, dev) if (words_a or words_b) else None
+    hoa, woa = conv_out_hw(da)
+    hob, wob = conv_out_hw(db)
+    ya = torch.empty((da.N, hoa, woa, da.Cout), dtype=torch.float32, device=dev)
+    yb = torch.empty((db.N, hob, wob, db.Cout), dtype=torch.float32, device=dev)
+    G, parts = a["gn_groups"], a["gn_parts"]
+    partial = torch.empty((da.N, parts, G, 2), dtype=torch.float64, device=dev)
+    slots = torch.empty((db.N, slots_b), dtype=torch.float32, device=dev) if slots_b else None
+    (wa, wmax_a), (wb, wmax_b) = a["w_split"], b["w_split"]
+    ca = L.MfConvF16x2Call(x1s.data_ptr(), _ptr(x2s), wa.data_ptr(), _ptr(a["bias"]), ya.data_ptr(), b1.data_ptr(), _ptr(b2), wmax_a, None,
+                           ws.data_ptr() if need_a else None, need_a, sync.data_ptr() if words_a else None, partial.data_ptr(), G, C.pointer(da))
+    cb = L.MfConvF16x2Call(x1s.data_ptr(), _ptr(x2s), wb.data_ptr(), _ptr(b["bias"]), yb.data_ptr(), b1.data_ptr(), _ptr(b2), wmax_b, _ptr(slots),
+                           ws.data_ptr() + off_b if need_b else None, need_b, sync.data_ptr() + 4 * words_a if words_b else None, None, 0, C.pointer(db))
+    L.check(lib.mf_conv2d_f16x2_group(C.byref(ca), C.byref(cb), stream()), "mf_conv2d_f16x2_group")
+    if slots_b:
+        yb._mf_slots = slots
+        _stamp(yb)
+    return (ya, partial), yb
+
+
 def pack_nchw_pairs(x_nchw: torch.Tensor, cp: int = 32) -> torch.Tensor:
     """NCHW fp32 [N, C, H, W] (C <= cp) -> an NHWC [N, H, W, cp] tensor that exists ONLY as fp16 pairs (channels C.. zero), scaled per sample by
     the max |x| the same launch measures (mf_pack_nchw_pairs_f32): the operand form of the network input"""

@@ -40,6 +40,13 @@ class MfGnFuse(C.Structure):
                 ("emb_stride", C.c_int64), ("res_nslots", C.c_int32), ("act", C.c_int32), ("bconst", C.c_float), ("eps", C.c_float)]
 
 
+class MfConvF16x2Call(C.Structure):
+    """the arguments of one mf_conv2d_f16x2 call (mf_conv2d_f16x2_group takes two)"""
+    _fields_ = [("x1s", c_fp), ("x2s", c_fp), ("ws", c_fp), ("bias", c_fp), ("y", c_fp), ("x1_bound", c_fp), ("x2_bound", c_fp), ("w_bound", C.c_float),
+                ("y_bound", c_fp), ("workspace", c_fp), ("workspace_bytes", C.c_size_t), ("sync", c_fp), ("gn_partial", c_fp), ("G", C.c_int32),
+                ("d", C.POINTER(MfConvDesc))]
+
+
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc", "conv_gn_fused")
 
@@ -64,6 +71,8 @@ _SIGS = {
     "mf_conv2d_f16x2_pairs_out": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, _F, _F, _F, c_fp, _SZ, c_fp, C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_fuse_words": (_I, [C.POINTER(MfConvDesc), _I]),
     "mf_conv2d_f16x2_gn_apply": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfGnFuse), C.POINTER(MfConvDesc), c_fp]),
+    "mf_conv2d_f16x2_group_ok": (_I, [C.POINTER(MfConvDesc), _I, C.POINTER(MfConvDesc), _I]),
+    "mf_conv2d_f16x2_group": (_I, [C.POINTER(MfConvF16x2Call), C.POINTER(MfConvF16x2Call), c_fp]),
     "mf_maxabs_rows_slots": (_I, [_I64]),
     "mf_maxabs_rows_f32": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
     "mf_bound_finalize_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),

@@ -31,8 +31,8 @@ for k, v in tab.items():
 out.sort(key=lambda e: -e["total_fetch_KiB_raw"])
 # per-tile breakdown of the conv kernel's fetches against what ONE pass over its operands would move: the bench's conv
 # launches by tile instantiation, fetched bytes / launch next to written bytes / launch
-tiles = [{"tile": e["kernel"].split("<")[1].split(">")[0], "launches": e["launches"], "fetch_MB_per_launch": round(2 * e["fetch_KiB_avg_raw"] * 1024 / 1e6, 2),
-          "write_MB_per_launch": round(e["write_KiB_avg_raw"] * 1024 / 1e6, 2)} for e in out if "conv_f16x2_kernel<" in e["kernel"] or "conv_halo_kernel<" in e["kernel"]]
+tiles = [{"tile": e["kernel"][e["kernel"].index("<") + 1:e["kernel"].rindex(">")], "launches": e["launches"], "fetch_MB_per_launch": round(2 * e["fetch_KiB_avg_raw"] * 1024 / 1e6, 2),
+          "write_MB_per_launch": round(e["write_KiB_avg_raw"] * 1024 / 1e6, 2)} for e in out if "conv_f16x2_kernel<" in e["kernel"] or "conv_halo_kernel<" in e["kernel"] or "conv_group_kernel<" in e["kernel"]]
 json.dump({"command": "bench.py --steps 1 --warmup 0 (cfg2: B=16, 150 iterations + decode, default conv arithmetic)",
            "conv_source_stamp": conv_source_stamp(), "conv_tiles": tiles,
            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction)",

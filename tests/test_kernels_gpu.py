@@ -1320,3 +1320,66 @@ def test_packed_fp32_twin_of_the_convolution(dev):
     bad, out = _stress_subprocess({"MEDFUSION_LIB": str(twin)}, ["--reps", "300", "--tiles", "53,54,36"])
     print(f"packed-fp32 twin: {flagged} flagged instructions, {bad} bad launches of the stress")
     assert bad == 0 or flagged > 0, out[-3000:]
+
+
+from tests.util import GROUP_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", GROUP_CASES)
+def test_two_convolutions_in_one_launch_equal_the_two_launches(dev, case):
+    """mf_conv2d_f16x2_group (round 4): the 3x3 of a channel-changing ResBlock with GroupNorm records and its conv_res 1x1 with measured bound
+    slots, both on the same (two-source) input, in ONE launch -- outputs, records and slots bit-identical to the two mf_conv2d_f16x2 launches,
+    on every host / guest tile pair that is instantiated (plain + plain, halo + plain, in-launch split-K on either side, an odd chunk count),
+    over repeated launches (the split-K counters come back to zero)."""
+    from medfusion_amd import kernels as K
+    n, h, w, c1, c2, co, ta, ska, tb = case
+    G = 32 if co >= 256 else 8
+    scale = torch.tensor([[1.0, 2.0 ** 9, 2.0 ** -7][i % 3] for i in range(n)]).view(n, 1, 1, 1)
+    x1 = K.nchw_to_nhwc((_rand(f"gx{case}", (n, c1, h, w)) * scale).to(dev))
+    x2 = K.nchw_to_nhwc((_rand(f"gy{case}", (n, c2, h, w)) * scale * 0.5).to(dev)) if c2 else None
+    w3 = _rand(f"gw3{case}", (co, c1 + c2, 3, 3), 1.0 / np.sqrt((c1 + c2) * 9)).to(dev)
+    w1 = _rand(f"gw1{case}", (co, c1 + c2, 1, 1), 1.0 / np.sqrt(c1 + c2)).to(dev)
+    b3, b1 = _rand(f"gb3{case}", (co,), 0.1).to(dev), _rand(f"gb1{case}", (co,), 0.1).to(dev)
+    wh3, wh1 = K.split_weight_f16x2(K.pack_conv_weight(w3)), K.split_weight_f16x2(K.pack_conv_weight(w1))
+    da = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 0, tile_hint=ta, splitk_hint=ska, precision=5)
+    db = K.make_conv_desc(n, h, w, c1, c2, co, 1, 1, 0, 0, tile_hint=tb, precision=5)
+    assert K.conv_f16x2_ok(da) and K.conv_f16x2_ok(db), case
+    pa, pb = K.pin_conv_plan(da), K.pin_conv_plan(db)
+    parts = K.conv_gn_parts(da, G)
+    assert parts > 0 and pb[1] > 0, case
+    assert K.conv_group_ok(da, G, db, 0), (case, K.conv_plan(da), K.conv_plan(db))
+    y_ref, part_ref = K.conv2d_f16x2(x1, wh3, b3, da, x2=x2, gn_groups=G, gn_parts=parts, pinned=pa)
+    r_ref = K.conv2d_f16x2(x1, wh1, b1, db, x2=x2, measure_out=True, pinned=pb)
+    for rep in range(3):
+        (y, part), r = K.conv2d_f16x2_group(x1, x2, dict(w_split=wh3, bias=b3, d=da, gn_groups=G, gn_parts=parts, pinned=pa), dict(w_split=wh1, bias=b1, d=db, pinned=pb))
+        assert torch.equal(y, y_ref), (case, rep, "3x3 output")
+        assert torch.equal(part, part_ref), (case, rep, "GroupNorm records")
+        assert torch.equal(r, r_ref), (case, rep, "1x1 output")
+        assert torch.equal(r._mf_slots, r_ref._mf_slots), (case, rep, "bound slots")
+    assert int(K.SyncWords.get(1, x1.device).abs().max()) == 0          # every split-K counter back at zero
+
+
+def test_grouped_conv_res_inside_the_blocks(dev):
+    """MEDFUSION_GROUPED_CONV_RES=1 (blocks.GROUPED_CONV_RES): a channel-changing BasicResBlock gives the same bits with conv_res inside the
+    3x3's launch, and falls back to two launches where the pair cannot share one (an odd shape)."""
+    from medfusion_amd import blocks as BLK
+    from medfusion_amd import kernels as K
+    blk = BLK.BasicResBlock(2, 256, 512, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {})).to(dev)
+    S.synth_state_dict(blk, "grp.")
+    x = K.nchw_to_nhwc(_rand("grpx", (16, 256, 16, 16)).to(dev))
+    emb = _rand("grpe", (16, 512)).to(dev)
+    old = BLK.GROUPED_CONV_RES
+    try:
+        BLK.GROUPED_CONV_RES = False
+        want = blk(x, emb=emb, emb_stride=512)
+        BLK.GROUPED_CONV_RES = True
+        got = blk(x, emb=emb, emb_stride=512)
+        assert blk._group and next(iter(blk._group.values())) is not None      # the pair shares a launch for this shape
+        assert torch.equal(got, want) and torch.equal(got._mf_split, want._mf_split) and torch.equal(got._mf_bound, want._mf_bound)
+        xo = K.nchw_to_nhwc(_rand("grpo", (2, 256, 10, 12)).to(dev))              # no instantiated pair for what the planner picks here, or it is: either way equal
+        BLK.GROUPED_CONV_RES = False
+        want_o = blk(xo, emb=emb[:2], emb_stride=512)
+        BLK.GROUPED_CONV_RES = True
+        assert torch.equal(blk(xo, emb=emb[:2], emb_stride=512), want_o)
+    finally:
+        BLK.GROUPED_CONV_RES = old

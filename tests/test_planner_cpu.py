@@ -184,3 +184,40 @@ def test_every_entry_of_the_plan_table_is_taken_as_written():
         if lib.mf_conv2d_f16x2_ok(C.byref(d)) != 1 or K.conv_plan(d) != (tile, sk):
             bad.append((r, K.conv_plan(d)))
     assert not bad, bad
+
+
+def test_which_pairs_of_convolutions_can_share_a_launch():
+    """mf_conv2d_f16x2_group_ok (host-side): every case of the GPU bit-equality test is a pair the library accepts; the seven channel-changing
+    ResBlocks of cfg2 (B = 16) all find a guest tile; refusals: a plan with a reducer pass behind it, workgroup sizes that differ, a reduced
+    precision, a pair that is not instantiated."""
+    from tests.util import GROUP_CASES
+    lib = L.load()
+    for n, h, w, c1, c2, co, ta, ska, tb in GROUP_CASES:
+        da = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 0, tile_hint=ta, splitk_hint=ska, precision=5)
+        db = K.make_conv_desc(n, h, w, c1, c2, co, 1, 1, 0, 0, tile_hint=tb, precision=5)
+        G = 32 if co >= 256 else 8
+        assert K.conv_f16x2_ok(da) and K.conv_f16x2_ok(db)
+        assert K.conv_gn_parts(da, G) > 0 and lib.mf_conv2d_f16x2_bound_slots(C.byref(db)) > 0
+        assert K.conv_group_ok(da, G, db, 0), ((n, h, w, c1, c2, co), K.conv_plan(da), K.conv_plan(db))
+    a = _d(16, 16, 16, 256, 0, 512, prec=5)                       # planner: tile 53 (4 waves)
+    assert K.conv_plan(a)[0] == 53
+    assert not K.conv_group_ok(a, 32, _d(16, 16, 16, 256, 0, 512, k=1, prec=5, tile=36), 0)     # 4-wave host, 8-wave guest
+    assert not K.conv_group_ok(a, 32, _d(16, 16, 16, 256, 0, 512, k=1, prec=6), 0)              # single-term guest
+    assert not K.conv_group_ok(_d(16, 16, 16, 256, 0, 512, prec=5, tile=53, sk=3), 32, _d(16, 16, 16, 256, 0, 512, k=1, prec=5), 0)   # 3 slices: slabs + reducer
+    assert not K.conv_group_ok(_d(16, 32, 32, 256, 0, 256, prec=5, tile=52, sk=1), 32, _d(16, 32, 32, 256, 0, 256, k=1, prec=5, tile=53), 0)  # (52, 53) is not instantiated
+    assert lib.mf_conv2d_f16x2_group(None, None, None) != 0 and b"conv_group" in lib.mf_last_error()
+
+
+def test_grouped_conv_res_finds_a_guest_tile_for_every_block_of_cfg2():
+    from medfusion_amd import blocks as BLK
+    import torch
+    shapes = [(16, 16, 16, 256, 0, 512), (16, 8, 8, 512, 0, 1024), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512), (16, 16, 16, 512, 512, 512),
+              (16, 16, 16, 512, 256, 256), (16, 32, 32, 256, 256, 256)]
+    for n, h, w, c1, c2, co in shapes:
+        blk = BLK.BasicResBlock(2, c1 + c2, co, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {}))
+        x1 = torch.empty((n, h, w, c1), device="meta")
+        x = x1 if not c2 else (x1, torch.empty((n, h, w, c2), device="meta"))
+        g = blk._grouped(x)
+        assert g is not None, (n, h, w, c1, c2, co)
+        ta, tb = K.conv_plan(g[0])[0], K.conv_plan(g[3])[0]
+        assert (ta in (53, 54) and tb == 53) or (ta in (34, 62) and tb in (36, 37)), (ta, tb)

@@ -62,3 +62,10 @@ def oracle_noise(seed: int):
 
     src = S.PhiloxNoise(seed)
     return M.HostNoise(lambda shape: src(torch.empty(tuple(shape))))
+
+
+# (N, H, W, C1, C2, Cout of both, tile / split-K hint of the 3x3 (0: planner), tile hint of the 1x1 (0: planner))
+GROUP_CASES = [(16, 16, 16, 256, 0, 512, 0, 0, 0), (16, 8, 8, 512, 0, 1024, 0, 0, 0), (16, 8, 8, 1024, 1024, 1024, 0, 0, 36), (16, 8, 8, 1024, 512, 512, 0, 0, 36),
+               (16, 16, 16, 512, 512, 512, 0, 0, 36), (16, 16, 16, 512, 256, 256, 0, 0, 36), (16, 32, 32, 256, 256, 256, 0, 0, 37),
+               (2, 16, 16, 64, 0, 128, 53, 1, 53), (3, 16, 16, 64, 32, 128, 54, 2, 53), (2, 16, 16, 128, 0, 256, 34, 2, 37), (2, 32, 32, 64, 64, 128, 62, 1, 36),
+               (3, 16, 16, 96, 0, 128, 34, 1, 36)]
