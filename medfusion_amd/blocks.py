@@ -109,9 +109,9 @@ PAIRS_ONLY_BETWEEN_BLOCKS = os.environ.get("MEDFUSION_PAIRS_ONLY", "1") != "0"  
 # (33.22 / 33.24 vs 33.23 / 33.32 images/s, two interleaved rounds: the 9-chunk matrix launch + the pack launch cost what the fp32 direct kernel
 # + the measuring / split passes cost) -- opt-in, MEDFUSION_INPUT_CONV_PAIRS=1
 INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "0") == "1"
-# conv_res in the launch of the block's 3x3 (mf_conv2d_f16x2_group; conv_f16x2_group.h).  Bit-identical to the two launches; UNMEASURED at the end
-# of round 4 (built after the round's GPU budget was spent) -- therefore opt-in, MEDFUSION_GROUPED_CONV_RES=1, until an A/B on the device decides
-GROUPED_CONV_RES = os.environ.get("MEDFUSION_GROUPED_CONV_RES", "0") == "1"
+# conv_res in the launch of the block's 3x3 (mf_conv2d_f16x2_group; conv_f16x2_group.h).  Bit-identical to the two launches and +2.2 % on the cfg2
+# step (same-process A/B, four interleaved rounds: 454.8 -> 444.9 ms, profiles/r04_grouped_conv_res_ab.txt).  MEDFUSION_GROUPED_CONV_RES=0: two launches (A/B)
+GROUPED_CONV_RES = os.environ.get("MEDFUSION_GROUPED_CONV_RES", "1") != "0"
 DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.

@@ -22,14 +22,21 @@ def run(steps, seed):
     return out
 
 
-BLK.GROUPED_CONV_RES = False
-a = pipe.sample(4, (8, 32, 32), steps=6, use_ddim=True, noise=M.PhiloxDeviceNoise(7))
-la = pipe.last_cmdlist_launches
-BLK.GROUPED_CONV_RES = True
-b = pipe.sample(4, (8, 32, 32), steps=6, use_ddim=True, noise=M.PhiloxDeviceNoise(7))
-lb = pipe.last_cmdlist_launches
-same = bool(torch.equal(a, b))
-print(f"images bit-identical: {same}; launches per recorded iteration {la} -> {lb}", flush=True)
+same, la, lb = True, 0, 0
+for bsz, loop in ((16, "cmdlist"), (16, "eager"), (8, "cmdlist")):     # (the pairs that share a launch depend on the batch: 11 at B = 16, 8 at B = 8)
+    BLK.GROUPED_CONV_RES = False
+    a = pipe.sample(bsz, (8, 32, 32), steps=6, use_ddim=True, noise=M.PhiloxDeviceNoise(7), loop=loop)
+    l0 = pipe.last_cmdlist_launches
+    BLK.GROUPED_CONV_RES = True
+    b = pipe.sample(bsz, (8, 32, 32), steps=6, use_ddim=True, noise=M.PhiloxDeviceNoise(7), loop=loop)
+    l1 = pipe.last_cmdlist_launches
+    eq = bool(torch.equal(a, b))
+    same = same and eq
+    if (bsz, loop) == (16, "cmdlist"):
+        la, lb = l0, l1
+    print(f"B = {bsz}, loop {loop}: images bit-identical: {eq}; launches per recorded iteration {l0} -> {l1}", flush=True)
+if ROUNDS == 0:
+    sys.exit(0 if same else 1)
 res = {False: [], True: []}
 for r in range(ROUNDS):
     for on in (False, True):

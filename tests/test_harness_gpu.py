@@ -187,7 +187,7 @@ def test_cfg4_graph_replay_at_full_size(dev, conv_precision):
     graph = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), use_graph=True, **kw)
     assert torch.equal(eager, graph)
     listed = pipe.sample(8, (8, 32, 32), steps=100, noise=M.PhiloxDeviceNoise(4), loop="cmdlist", **kw)    # the default loop of sample()
-    assert torch.equal(eager, listed) and pipe.last_cmdlist_launches > 80    # (the whole iteration: 98 launches at this revision)
+    assert torch.equal(eager, listed) and pipe.last_cmdlist_launches > 60    # (the whole iteration: 84 launches at this revision -- 92 minus the 8 conv_res that share their 3x3's launch at B = 8)
     if conv_precision == 5:
         src = M.PhiloxDeviceNoise(4)
         img = pipe.sample(8, (8, 32, 32), steps=None, use_ddim=False, noise=src, use_graph=True)
