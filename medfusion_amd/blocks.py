@@ -428,10 +428,14 @@ class BasicResBlock(nn.Module):
                 m = n * ((h + 2 * cr.pad - cr.k) // cr.stride + 1) * ((w + 2 * cr.pad - cr.k) // cr.stride + 1)
                 t36, t37 = -(-m // 128) * (cr.out_ch // 64), -(-m // 64) * max(cr.out_ch // 256, 1)
                 wide = (36, 37) if abs(t36 - 256) <= abs(t37 - 256) or cr.out_ch % 256 else (37, 36)
+                # (the guest keeps the SPLIT-K of the plan it has alone: the tile only partitions pixels and output channels, but the number of
+                # K slices is the summation order -- with it fixed, the block gives the same bits whether or not the pair shares a launch)
+                nat = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, precision=5)
+                sk0 = K.conv_plan(nat)[1] if K.conv_f16x2_ok(nat) else 0
                 for tile in (0, *wide, 53):
-                    if tile == 37 and cr.out_ch % 256:
+                    if (tile == 37 and cr.out_ch % 256) or sk0 <= 0:
                         continue
-                    db = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, tile_hint=tile, precision=5)
+                    db = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, tile_hint=tile, splitk_hint=sk0 if tile else 0, precision=5)
                     if not K.conv_f16x2_ok(db):
                         continue
                     pb = K.pin_conv_plan(db)
