@@ -221,3 +221,30 @@ def test_grouped_conv_res_finds_a_guest_tile_for_every_block_of_cfg2():
         assert g is not None, (n, h, w, c1, c2, co)
         ta, tb = K.conv_plan(g[0])[0], K.conv_plan(g[3])[0]
         assert (ta in (53, 54) and tb == 53) or (ta in (34, 62) and tb in (36, 37)), (ta, tb)
+
+
+def test_grouped_launch_refuses_shared_scratch_before_launching():
+    """mf_conv2d_f16x2_group checks, on the host and before any launch, that two convolutions which both meet their split-K slices inside the
+    launch have their OWN hand-off regions and counters, and their own outputs (the pointers are never dereferenced on the host: dummies)."""
+    lib = L.load()
+    da = K.make_conv_desc(16, 8, 8, 1024, 1024, 1024, 3, 1, 1, 0, precision=5)               # planner: halo tile 62, 8 slices (in-launch tree)
+    db = K.make_conv_desc(16, 8, 8, 1024, 1024, 1024, 1, 1, 0, 0, tile_hint=36, splitk_hint=2, precision=5)
+    assert K.conv_group_ok(da, 32, db, 0)
+    na, nb = lib.mf_conv2d_workspace_bytes(C.byref(da)), lib.mf_conv2d_workspace_bytes(C.byref(db))
+    wa, wb = lib.mf_conv2d_f16x2_sync_words(C.byref(da)), lib.mf_conv2d_f16x2_sync_words(C.byref(db))
+    assert na > 0 and nb > 0 and wa > 0 and wb > 0
+    base = 1 << 40   # a made-up device address
+
+    def call(d, y, ws, need, sync, partial, G, slots):
+        return L.MfConvF16x2Call(base, base + (1 << 30), base + (2 << 30), None, y, base + (3 << 30), base + (3 << 30) + 4096, 1.0, slots, ws, need, sync, partial, G,
+                                 C.pointer(d))
+
+    ya, yb, ws, sy = base + (4 << 30), base + (5 << 30), base + (6 << 30), base + (7 << 30)
+    a = call(da, ya, ws, na, sy, base + (8 << 30), 32, None)
+    for b, what in ((call(db, yb, ws + na // 2, nb, sy + 4 * wa, None, 0, base + (9 << 30)), b"workspaces overlap"),
+                    (call(db, yb, ws + na, nb, sy + 4 * (wa - 1), None, 0, base + (9 << 30)), b"sync arrays overlap"),
+                    (call(db, ya, ws + na, nb, sy + 4 * wa, None, 0, base + (9 << 30)), b"one output")):
+        assert lib.mf_conv2d_f16x2_group(C.byref(a), C.byref(b), None) != 0
+        assert what in lib.mf_last_error(), lib.mf_last_error()
+    small = call(db, yb, ws + na, nb // 2, sy + 4 * wa, None, 0, base + (9 << 30))              # a workspace that is too small: the ordinary check
+    assert lib.mf_conv2d_f16x2_group(C.byref(a), C.byref(small), None) != 0 and b"workspace" in lib.mf_last_error()
