@@ -248,3 +248,26 @@ def test_grouped_launch_refuses_shared_scratch_before_launching():
         assert what in lib.mf_last_error(), lib.mf_last_error()
     small = call(db, yb, ws + na, nb // 2, sy + 4 * wa, None, 0, base + (9 << 30))              # a workspace that is too small: the ordinary check
     assert lib.mf_conv2d_f16x2_group(C.byref(a), C.byref(small), None) != 0 and b"workspace" in lib.mf_last_error()
+
+
+def test_group_guest_override_hook():
+    """blocks.GROUP_GUEST (scripts/group_tune.py): -1 keeps a block on two launches, a tile id forces that guest (None when the pair does not
+    exist), and in every case the guest runs the split-K it has alone"""
+    from medfusion_amd import blocks as BLK
+    import torch
+    blk = BLK.BasicResBlock(2, 512, 256, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {}))
+    x = (torch.empty((16, 32, 32, 256), device="meta"), torch.empty((16, 32, 32, 256), device="meta"))
+    key = (16, 32, 32, 256, 256, 256)
+    alone = K.conv_plan(K.make_conv_desc(16, 32, 32, 256, 256, 256, 1, 1, 0, 0, precision=5))
+    try:
+        g = blk._grouped(x)
+        assert g is not None and K.conv_plan(g[3])[1] == alone[1]
+        for forced, want in ((-1, None), (36, 36), (53, None)):          # host: the 8-wave halo tile -> a 4-wave guest is not a pair
+            BLK.GROUP_GUEST[key] = forced
+            blk._group.clear()
+            g = blk._grouped(x)
+            assert (g is None) == (want is None), forced
+            if want:
+                assert K.conv_plan(g[3]) == (want, alone[1])
+    finally:
+        BLK.GROUP_GUEST.clear()
