@@ -112,7 +112,7 @@ INPUT_CONV_ON_PAIRS = os.environ.get("MEDFUSION_INPUT_CONV_PAIRS", "0") == "1"
 # conv_res in the launch of the block's 3x3 (mf_conv2d_f16x2_group; conv_f16x2_group.h).  Bit-identical to the two launches and +2.2 % on the cfg2
 # step (same-process A/B, four interleaved rounds: 454.8 -> 444.9 ms, profiles/r04_grouped_conv_res_ab.txt).  MEDFUSION_GROUPED_CONV_RES=0: two launches (A/B)
 GROUPED_CONV_RES = os.environ.get("MEDFUSION_GROUPED_CONV_RES", "1") != "0"
-GROUP_GUEST = {}   # tuning hook (scripts/group_tune.py): (N, H, W, C1, C2, Cout) -> guest tile to take for that block, or -1 = two launches; empty in the product
+GROUP_GUEST = {}   # tuning hook (scripts/group_tune.py): (N, H, W, C1, C2, Cout) -> guest tile (or (tile, split-K)) for that block, -1 = two launches; empty in the product
 DERIVED_OUT_BOUNDS = os.environ.get("MEDFUSION_DERIVED_BOUNDS", "1") != "0"   # (A/B switch of mf_conv2d_f16x2_pairs_out behind down / up convolutions)
 SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent) form whenever the shape allows
 # Arithmetic of the implicit-GEMM convolutions (include/medfusion_hip.h, MF_CONV_*); read per call: set blocks.CONV_PRECISION or the env var.
@@ -434,6 +434,8 @@ class BasicResBlock(nn.Module):
                 nat = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, precision=5)
                 sk0 = K.conv_plan(nat)[1] if K.conv_f16x2_ok(nat) else 0
                 forced = GROUP_GUEST.get((n, h, w, c1, c2, cr.out_ch))
+                if isinstance(forced, tuple):      # (tile, split-K): the tuner may also try another summation order (same value to fp32 rounding)
+                    forced, sk0 = forced
                 for tile in ((0, *wide, 53) if forced is None else () if forced < 0 else (forced,)):
                     if (tile == 37 and cr.out_ch % 256) or sk0 <= 0:
                         continue

@@ -52,7 +52,7 @@ print(f"grouped-launch tuning, denoise loop (B = {a.batch}, latent {a.latent}, 1
 for key, cur in keys.items():
     res = {}
     for rnd in range(2):
-        for choice in (None, -1, 36, 37, 53):
+        for choice in (None, -1, 36, 37, 53, (36, 1), (36, 2), (36, 4), (37, 1), (37, 2), (53, 1), (53, 2)):
             if choice is None:
                 BLK.GROUP_GUEST.pop(key, None)
             else:
@@ -74,11 +74,11 @@ for key, cur in keys.items():
     for c, v in res.items():
         if c is None:
             continue
-        line += f" {'two launches' if c == -1 else 'guest %d' % c}: {v[0]:7.2f} {v[1]:7.2f}"
+        line += f" {'two launches' if c == -1 else 'guest %s' % (c,)}: {v[0]:7.2f} {v[1]:7.2f}"
         if v[0] < base[0] * 0.9985 and v[1] < base[1] * 0.9985 and (best is None or sum(v) < sum(res[best])):
             best = c
     if best is not None:
-        line += f"  -> {'two launches' if best == -1 else 'guest %d' % best} ({100 * (sum(base) / sum(res[best]) - 1):+.2f} %)"
+        line += f"  -> {'two launches' if best == -1 else 'guest %s' % (best,)} ({100 * (sum(base) / sum(res[best]) - 1):+.2f} %)"
         BLK.GROUP_GUEST[key] = best      # keep it: later blocks are tuned on top of it
     print(line, flush=True)
 print("overrides that beat the host logic:", dict(BLK.GROUP_GUEST))
