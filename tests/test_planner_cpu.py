@@ -271,3 +271,67 @@ def test_group_guest_override_hook():
                 assert K.conv_plan(g[3]) == (want, alone[1])
     finally:
         BLK.GROUP_GUEST.clear()
+
+
+def test_pair_planner_properties_over_many_descriptors():
+    """randomised sweep of the fp16-pair planner through the C-ABI (host only), with and without hints: a plan is a known tile whose BN divides
+    Cout and a split-K that leaves every slice at least one chunk and at most 96 chunk-taps unless hinted; the scratch sizes follow the plan
+    (in-launch tree: hand-off slots and one counter per pair and level; otherwise whole output slabs); whoever can emit GroupNorm records or
+    bound slots says how many; a pair that may share a launch consists of two plans that finish inside their launch."""
+    import random
+    lib = L.load()
+    rnd = random.Random(4321)
+    tiles = {31: (128, 256, 8), 32: (256, 128, 8), 33: (128, 128, 8), 34: (128, 128, 8), 35: (256, 64, 8), 36: (128, 64, 8), 37: (64, 256, 8), 51: (128, 128, 4),
+             52: (128, 128, 4), 53: (64, 128, 4), 54: (128, 64, 4), 61: (256, 128, 8), 62: (256, 128, 8), 63: (128, 128, 8), 64: (128, 128, 8)}
+    n_ok = n_tree = n_group = 0
+    for _ in range(600):
+        n = rnd.choice([1, 2, 3, 8, 16, 32])
+        h = rnd.choice([4, 8, 10, 16, 32, 64])
+        w = rnd.choice([4, 8, 12, 16, 32, 64])
+        c1 = rnd.choice([32, 64, 96, 128, 256, 512, 1024])
+        c2 = rnd.choice([0, 0, 32, 256, 512, 1024])
+        co = rnd.choice([64, 128, 192, 256, 512, 1024])
+        k = rnd.choice([1, 3])
+        stride = rnd.choice([1, 1, 2])
+        ups = rnd.choice([0, 0, 2]) if (k == 3 and stride == 1) else 0
+        tile = rnd.choice([0, 0, 0] + list(tiles))
+        sk = rnd.choice([0, 0, 0, 1, 2, 3, 4, 8])
+        d = _d(n, h, w, c1, c2, co, k=k, stride=stride, ups=ups, prec=5, tile=tile, sk=sk)
+        if lib.mf_conv2d_f16x2_ok(C.byref(d)) != 1:
+            assert lib.mf_conv2d_f16x2_sync_words(C.byref(d)) == 0 and lib.mf_conv2d_f16x2_bound_slots(C.byref(d)) == 0
+            continue
+        n_ok += 1
+        t, s = K.conv_plan(d)
+        assert t in tiles and (tile == 0 or t == tile), (t, tile)
+        bm, bn, nw = tiles[t]
+        cg = (c1 + c2) // 32
+        assert co % bn == 0 and 1 <= s <= cg and (sk == 0 or s == min(sk, cg) or s == -(-cg // -(-cg // sk))), (t, s, sk, cg)
+        ho, wo = K.conv_out_hw(d)
+        m, out_bytes = n * ho * wo, n * ho * wo * co * 4
+        ws, words = lib.mf_conv2d_workspace_bytes(C.byref(d)), lib.mf_conv2d_f16x2_sync_words(C.byref(d))
+        tiles_mn = -(-m // bm) * (co // bn)
+        if s == 1:
+            assert ws == 0 and words == 0
+        elif words:                                   # the slices meet inside the launch
+            n_tree += 1
+            assert s & (s - 1) == 0 and words == tiles_mn * (s - 1)
+            assert ws >= tiles_mn * 2 * (s - 1) * bm * bn * 4 and ws >= s * out_bytes
+        else:
+            assert ws == s * out_bytes
+        for G in (8, 32):
+            if co % G:
+                continue
+            parts = lib.mf_conv2d_gn_parts(C.byref(d), G)
+            assert 0 <= parts <= max(ho * wo, 1)
+        slots = lib.mf_conv2d_f16x2_bound_slots(C.byref(d))
+        assert slots >= 0
+        # a 1x1 twin on the same input, as conv_res has one: if the pair may share a launch, both finish inside theirs
+        if k == 3 and stride == 1 and not ups:
+            g = _d(n, h, w, c1, c2, co, k=1, prec=5, tile=rnd.choice([0, 36, 37, 53]))
+            if lib.mf_conv2d_f16x2_ok(C.byref(g)) == 1 and K.conv_group_ok(d, 0, g, 0):
+                n_group += 1
+                for q in (d, g):
+                    tq, sq = K.conv_plan(q)
+                    assert sq == 1 or lib.mf_conv2d_f16x2_sync_words(C.byref(q)) > 0
+                assert tiles[K.conv_plan(d)[0]][2] == tiles[K.conv_plan(g)[0]][2]      # one workgroup size
+    assert n_ok > 200 and n_tree > 20 and n_group >= 1, (n_ok, n_tree, n_group)
