@@ -30,6 +30,35 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.MfSchedStep) == 12 * 4
     assert C.sizeof(L.MfSchedArgs) == 8 * 6 + 8 + 8 * 5 + 4 * 4 + 8  # 6 ptr, i64, 5 ptr, 3 i32 + f32, i64
     assert C.sizeof(L.MfGnFuse) == 8 * 13 + 8 + 4 * 4                   # 13 ptr, i64, 2 i32 + 2 f32
+    assert C.sizeof(L.MfConvF16x2Call) == 8 * 7 + 8 + 8 * 5 + 8 + 8           # 7 ptr, f32 (+ pad), 5 ptr / size_t, i32 (+ pad), ptr
+
+
+def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
+    """every struct of the header, field by field: gcc compiles include/medfusion_hip.h as C (a cgo / JNI binding would) and prints sizeof and
+    offsetof; the ctypes mirrors in medfusion_amd/lib.py must agree name by name"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from medfusion_amd import lib as L
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    structs = {"MfConvDesc": L.MfConvDesc, "MfSchedStep": L.MfSchedStep, "MfSchedArgs": L.MfSchedArgs, "MfGnFuse": L.MfGnFuse, "MfConvF16x2Call": L.MfConvF16x2Call}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "medfusion_hip.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{fname} %zu\\n", offsetof({name}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == C.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(got[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
 
 
 def test_host_validation_without_gpu():
