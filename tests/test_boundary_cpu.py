@@ -181,3 +181,43 @@ def test_command_list_host_contract():
     assert lib.mf_cmdlist_replay(empty, 3, None) == 0        # nothing recorded: nothing launched (no device needed)
     assert lib.mf_cmdlist_replay(None, 1, None) != 0 and lib.mf_cmdlist_replay(empty, -1, None) != 0
     assert lib.mf_cmdlist_free(h) == 0 and lib.mf_cmdlist_free(empty) == 0
+
+
+def test_a_plain_c_program_links_and_calls_the_library(tmp_path):
+    """the boundary is a C ABI, not a ctypes convention: a C11 program that includes include/medfusion_hip.h links against
+    libmedfusion_hip.so and calls host-side entry points (version, planner query, capability, error string) -- what a cgo / JNI stub would do"""
+    import shutil
+    import subprocess
+    from medfusion_amd import build as B, lib as L
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    L.load()   # (built)
+    src = tmp_path / "prog.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "medfusion_hip.h"
+int main(void) {
+  MfConvDesc d;
+  memset(&d, 0, sizeof d);
+  d.N = 16; d.Hin = 32; d.Win = 32; d.C1 = 256; d.C2 = 0; d.Cout = 256; d.KH = 3; d.KW = 3; d.stride = 1; d.pad = 1;
+  d.in_layout = MF_LAYOUT_NHWC; d.out_layout = MF_LAYOUT_NHWC; d.precision = MF_CONV_FP32_F16X2;
+  int32_t tile = 0, sk = 0;
+  int rc = mf_conv2d_plan_query(&d, &tile, &sk);
+  printf("%d %d %d %d %d\n", mf_version(), rc, mf_conv2d_f16x2_ok(&d), (int)tile, (int)sk);
+  d.KH = 5;
+  printf("%d|%s\n", mf_conv2d_f16x2_ok(&d), mf_last_error());
+  return 0;
+}
+''')
+    exe = tmp_path / "prog"
+    libdir = B.LIB.parent
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), f"-L{libdir}", f"-l:{B.LIB.name}", f"-Wl,-rpath,{libdir}",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    ver, rc, ok, tile, sk = map(int, out[0].split())
+    from medfusion_amd import kernels as K
+    want = K.conv_plan(K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5))
+    assert (ver, rc, ok) == (220, 0, 1) and (tile, sk) == want
+    assert out[1].startswith("0|") and "unsupported" in out[1]
