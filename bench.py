@@ -47,7 +47,7 @@ ARITH = {
     4: dict(kernel="conv_igemm_kernel<..., MODE 5>", pmc_match=("conv_igemm_kernel<", ", 5, "), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),
-    5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN>", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS,
+    5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN> (+ its halo form conv_halo_kernel and conv_group_kernel: conv_res in the grid of its ResBlock's 3x3)", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS,
             dtype="f32 (emulated: fp16 pairs, 23-bit operands)",
             text="fp32 EMULATED through PAIRS of fp16: every operand stored as hi + lo/2048 (23 of 24 significand bits, error <= one fp32 ulp, zero for 3 values "
                  "of 4), 3 product terms on v_mfma_f32_32x32x16_f16 (the lo*lo term is dropped), fp32 accumulate; both operands moved HBM->LDS by "
