@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 220 /* 0.2.2 */
+#define MF_VERSION 230 /* 0.2.3 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -205,6 +205,61 @@ int mf_conv2d_f16x2_pairs_out_ok(const MfConvDesc* d);
 int mf_conv2d_f16x2_pairs_out(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, void* y_split, float* y_bound_out,
                               const float* x1_bound, const float* x2_bound, float w_bound, float w_l1_1, float w_l1_2, float bias_max,
                               void* workspace, size_t workspace_bytes, uint32_t* sync, const MfConvDesc* d, void* stream);
+
+/* --- Winograd F(2x2, 3x3) form of the 3x3 stride-1 pad-1 convolutions on the fp16-pair arithmetic (ABI 230; conv_blocks.py:185 as reached
+ * from unet2.py:250-264 -- the 3x3 convolutions of the UnetResBlocks, 94.4 % of the UNet's FLOPs).
+ *   y = A^T [ sum_c (G g G^T) . (B^T d B) ] A   per 2x2 output tile: 16 products per (tile, channel pair) instead of 36 (2.25x fewer matrix
+ * instructions).  The 16 element-wise products summed over the input channels are 16 independent GEMMs; they run on the kernel of
+ * mf_conv2d_f16x2 (fp16-pair operands, three product terms, fp32 accumulate, in-launch split-K tree), each row block with the weight slab of
+ * its component.  Same values as the direct form to fp32 rounding -- a DIFFERENT summation, not the same bits (error vs fp64 in
+ * profiles/r05_winograd_ab.txt); MF_CONV_FP32 / MF_CONV_FP32_SPLIT3_W3 (the exact arithmetics) never take this form.
+ *  mf_wino_ok(d): can `d` (3x3, stride 1, pad 1, upsample 0, NHWC, precision MF_CONV_FP32_F16X2, H and W even, C1 % 32 == C2 % 32 == 0,
+ *    Cout in {64, 128, 256, 512, 1024}) run so?  mf_wino_preferred(d): ... AND did it measure faster than the direct form on MI355X for this
+ *    exact shape (built-in table, csrc/wino_plan_table.inc)?
+ *  mf_wino_pack_weight_f32: OIHW 3x3 -> U = G g G^T, [16 components][Cout][Cin] fp32 (fp64 arithmetic, one rounding); split it with
+ *    mf_split_f16x2(rows = 1, bound = max |U|) like any packed weight.
+ *  mf_wino_input_f16x2: the fp16-pair form xs of an NHWC activation (scaled per sample by x_bound[N]) -> V = B^T d B as fp16 pairs
+ *    [16][N][(H/2)(W/2)][C], component k of sample n scaled by v_bound[k N + n] = 4 x_bound[n] (v_bound: 16 N floats, written).
+ *  mf_conv2d_wino_f16x2: v1s / v2s (the second source of a fused channel concat, or NULL) with their v*_bound arrays, us = the split U with the
+ *    scalar u_bound it was split with; y fp32 NHWC [N][H][W][Cout] = conv3x3(x1 ++ x2) + bias.  gn_partial optional: [N][parts][G][2] doubles,
+ *    parts = mf_wino_gn_parts(d, G) > 0 -- the records mf_gn_apply_from_partials_* reads.  workspace >= mf_wino_workspace_bytes(d) (the GEMM's
+ *    output in the transform domain + its split-K hand-off region), sync = mf_wino_sync_words(d) zero-initialised words as for mf_conv2d_f16x2.
+ *    d->tile_hint / splitk_hint address the component GEMM.  Two launches: the GEMM, then A^T M A + bias + statistics. */
+int mf_wino_ok(const MfConvDesc* d);
+int mf_wino_preferred(const MfConvDesc* d);
+int mf_wino_pack_weight_f32(const float* w_oihw, float* u, int Cout, int Cin, void* stream);
+int mf_wino_input_f16x2(const void* xs, const float* x_bound, void* vs, float* v_bound, int N, int H, int W, int C, void* stream);
+size_t mf_wino_workspace_bytes(const MfConvDesc* d);
+int mf_wino_sync_words(const MfConvDesc* d);
+int mf_wino_gn_parts(const MfConvDesc* d, int G);
+int mf_wino_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
+int mf_conv2d_wino_f16x2(const void* v1s, const void* v2s, const void* us, const float* bias, float* y, const float* v1_bound, const float* v2_bound,
+                         float u_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G, const MfConvDesc* d,
+                         void* stream);
+/* The Winograd convolution WITH what follows it in a ResBlock (BasicBlock.forward / BasicResBlock.forward, conv_blocks.py:185-191,236-240, and
+ * the `x += emb` of :360-363): GroupNorm(G) + Swish + residual + embedding row -- and, optionally, the INPUT TRANSFORM of the next Winograd
+ * convolution -- in the launch behind the GEMM: one workgroup per (sample, group) holds all pixels of the sample x the group's channels in LDS,
+ * so the statistics are complete inside the workgroup (no records, no apply pass, no un-normalised y in memory).  Outputs, each optional: `out`
+ * fp32 NHWC, `out_split` its fp16-pair form scaled per sample by out_bound[n] = bconst + bound(residual) + bound(embedding row) (as
+ * mf_gn_apply_from_partials_pairs_f32 derives it), `out_wino` = B^T d B of the result as mf_wino_input_f16x2 would make it from out_split (bit
+ * for bit; [16][N][(H/2)(W/2)][Cout], wino_bound: 16 N floats).  mf_wino_tail_ok(d, G): mf_wino_ok(d), whole 8-channel groups per GroupNorm
+ * group and H W (Cout / G) floats <= 64 KB.  The per-element arithmetic is that of the apply pass; the statistics are summed in another order
+ * than the records of mf_conv2d_wino_f16x2 (same values to fp64 rounding). */
+typedef struct MfWinoTail {
+  const float* gamma; const float* beta;                    /* [Cout], both or neither */
+  const float* residual; const void* residual_pairs;         /* fp32 NHWC, or fp16 pairs scaled by res_bound, or neither */
+  const float* res_bound; const float* res_bound_slots;      /* [N], or [N][res_nslots] slot maxima (mf_conv2d_f16x2 y_bound) */
+  const float* emb; const float* emb_bound;                  /* [N][emb_stride] rows added per (n, c) + their bounds [N], or NULL */
+  float* out; void* out_split; float* out_bound;
+  void* out_wino; float* wino_bound;
+  int64_t emb_stride;
+  int32_t res_nslots, act;                                   /* act 1: Swish */
+  float bconst, eps;                                         /* bconst >= max |act(gn(y) gamma + beta)| (host constant), GroupNorm eps */
+} MfWinoTail;
+int mf_wino_tail_ok(const MfConvDesc* d, int G);
+int mf_conv2d_wino_gn_apply_f16x2(const void* v1s, const void* v2s, const void* us, const float* bias, const float* v1_bound, const float* v2_bound,
+                                  float u_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, int G, const MfWinoTail* t,
+                                  const MfConvDesc* d, void* stream);
 
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},
@@ -412,7 +467,7 @@ int mf_image_egress_u8(const float* x_nchw, uint8_t* out_nhwc, float* minmax_ws,
  * When enabled every launch is bracketed by hipEvents on its own stream and attributed to a kernel family.
  * NOT capture-safe; off by default. */
 enum { MF_FAM_CONV_IGEMM = 0, MF_FAM_CONV_DIRECT, MF_FAM_SPLITK_REDUCE, MF_FAM_GN_STATS, MF_FAM_GN_APPLY, MF_FAM_LINEAR,
-       MF_FAM_SCHED, MF_FAM_NOISE, MF_FAM_ATTENTION, MF_FAM_MISC, MF_FAM_CONV_GN_FUSED, MF_FAM_COUNT };
+       MF_FAM_SCHED, MF_FAM_NOISE, MF_FAM_ATTENTION, MF_FAM_MISC, MF_FAM_CONV_GN_FUSED, MF_FAM_WINO_XFORM, MF_FAM_COUNT };
 int mf_prof_enable(int on);
 int mf_prof_reset(void);
 /* synchronises outstanding events; returns summed ms, launch count, algorithmic flops and bytes of a family */

@@ -51,6 +51,7 @@ class _Packed:
         self._w3 = None
         self._wb = None
         self._wh = None
+        self._wu = None
         self._l1 = {}
         self._subpixel = subpixel
 
@@ -66,9 +67,18 @@ class _Packed:
             self._w3 = None
             self._wb = None
             self._wh = None
+            self._wu = None
             self._l1 = {}
+            self._raw = w
             self._key = key
         return self._w
+
+    def get_wino(self, weight: torch.Tensor):
+        """the Winograd-domain weights U = G g G^T of a 3x3 convolution as fp16 pairs (mf_wino_pack_weight_f32, then split like any weight)"""
+        self.get(weight)
+        if self._wu is None:
+            self._wu = K.split_weight_f16x2(K.wino_pack_weight(self._raw))
+        return self._wu
 
     def get_f16x2(self, weight: torch.Tensor) -> torch.Tensor:
         """the same weights as fp16 pairs (MF_CONV_FP32_F16X2), derived once from the fp32 packing"""
@@ -125,6 +135,24 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #   6 opt-in REDUCED precision on the LDS-DMA kernel of 5: the same fp16-pair operands, ONE product term (operands rounded to fp16, 11 bits;
 #     MF_CONV_F16) -- its own tolerance, never a default, never the headline.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "5"))
+# Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolutions (arithmetic 5 only; kernels.conv2d_wino_f16x2): 0 never, 1 (default) the shapes of
+# csrc/wino_plan_table.inc -- those it measured faster on -- 2 wherever the library can (tests, sweeps).  Read per call like CONV_PRECISION.
+WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
+
+
+WINO_TAIL = os.environ.get("MEDFUSION_WINOGRAD_TAIL", "1") != "0"   # the GroupNorm / Swish / residual / embedding tail in the launch behind the GEMM (A/B switch; 0: three launches)
+WINO_SHAPES = {}   # tuning hook (scripts/wino_sweep.py / wino_ab.py): (N, H, W, Cin, Cout) -> (tile, split-K) of the component GEMM (0: planner); empty in the product
+if os.environ.get("MEDFUSION_WINOGRAD_TABLE"):   # a JSON list of [N, H, W, Cin, Cout, tile, split-K] (what the sweep writes), for A/B runs without a rebuild
+    import json as _json
+    WINO_SHAPES = {tuple(e[:5]): (int(e[5]), int(e[6])) for e in _json.load(open(os.environ["MEDFUSION_WINOGRAD_TABLE"]))}
+
+
+def wino_wanted(d) -> bool:
+    if WINOGRAD == 0:
+        return False
+    if (d.N, d.Hin, d.Win, d.C1 + d.C2, d.Cout) in WINO_SHAPES:
+        return K.wino_ok(d)
+    return K.wino_ok(d) if WINOGRAD == 2 else K.wino_preferred(d)
 
 
 def f16x2_mode() -> bool:
@@ -146,22 +174,35 @@ class Conv(nn.Module):
         self._pad_ok = {}
         self._descs = {}
         self._pairs_out = {}
+        self._wino_sites = {}     # shape key -> a consumer transformed this output into the Winograd domain: write V in the tail from now on
         self._bmax = (None, 0.0)
 
     def _forward_f16x2(self, x1, x2, n, h, w, c1, c2, out, gn_groups, gn_eps, measure_out, prec=5, derive_out=False, cin_pad=0):
         """MF_CONV_FP32_F16X2 (prec 5) / MF_CONV_F16 (prec 6), or None when this convolution is not on that kernel.
         cin_pad: the weights zero-padded to that many input channels (the input convolution on a padded pair operand)"""
-        key = ("f16x2", n, h, w, c1, c2, gn_groups, prec)
+        key = ("f16x2", n, h, w, c1, c2, gn_groups, prec, WINOGRAD)
         ent = self._descs.get(key)
         if ent is None:
             d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 2 if self.upsample else 0, precision=prec)
             ok = K.conv_f16x2_ok(d)
             pinned = K.pin_conv_plan(d) if ok else None     # (tile, split-K) fixed in the descriptor: per-launch planning is a field read
-            ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok, pinned)
+            wino = None
+            if ok and prec == 5 and not cin_pad and self.k == 3 and wino_wanted(d):
+                # the Winograd form measured faster for this exact shape (csrc/wino_plan_table.inc): 2.25x fewer matrix instructions
+                wparts = K.wino_gn_parts(d, gn_groups) if gn_groups else 0
+                if not gn_groups or wparts > 0:
+                    wt, wsk = WINO_SHAPES.get((n, h, w, c1 + c2, self.out_ch), (0, 0))
+                    wd = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 0, tile_hint=wt, splitk_hint=wsk, precision=prec)   # (hints address the component GEMM)
+                    wino = (wd, wparts, K.pin_wino_plan(wd))
+            ent = (d, K.conv_gn_parts(d, gn_groups) if (ok and gn_groups) else 0, ok, pinned, wino)
             self._descs[key] = ent
-        d, parts, ok, pinned = ent
+        d, parts, ok, pinned, wino = ent
         if not ok:
             return None
+        if wino is not None and out is None and not measure_out and not derive_out:
+            wd, wparts, wpinned = wino
+            r = K.conv2d_wino_f16x2(x1, self._packed.get_wino(self.weight), self.bias, wd, x2=x2, gn_groups=gn_groups, gn_parts=wparts, pinned=wpinned)
+            return (r[0], K.GnPartials(r[1], wparts, gn_eps)) if gn_groups else r
         pk = self._packed_pad if cin_pad else (self._packed_sub if d.upsample == 2 else self._packed)
         wh = pk.get_f16x2(self.weight)
         if not gn_groups:
@@ -191,6 +232,37 @@ class Conv(nn.Module):
         if gn_groups <= 256:
             return y, K.GnPartials(partial, parts, gn_eps)
         return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)   # (more groups than a workgroup has threads)
+
+    def forward_wino_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst):
+        """conv -> GroupNorm -> Swish -> + residual -> + emb on the Winograd form, the tail in ONE launch behind the component GEMM
+        (mf_conv2d_wino_gn_apply_f16x2), or None when this convolution is not on that path for this shape.  The output carries its transform-domain
+        mirror as well once a Winograd convolution has asked for it (K.wino_input marks the site): the next call writes it in the tail."""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        if c1 + c2 != self.in_ch:
+            raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
+        G = norm.num_groups
+        key = ("wino_tail", n, h, w, c1, c2, G, WINOGRAD, WINO_TAIL)
+        ent = self._descs.get(key)
+        if ent is None:
+            ent = False
+            if WINO_TAIL and CONV_PRECISION == 5 and self.k == 3 and self.stride == 1 and not self.upsample:
+                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 0, precision=5)
+                if wino_wanted(d) and K.wino_tail_ok(d, G):
+                    wt, wsk = WINO_SHAPES.get((n, h, w, c1 + c2, self.out_ch), (0, 0))
+                    d.tile_hint, d.splitk_hint = wt, wsk
+                    ent = (d, K.pin_wino_plan(d))
+            self._descs[key] = ent
+        if ent is False:
+            return None
+        d, pinned = ent
+        want = self._wino_sites.get(key, False)
+        y = K.conv2d_wino_gn_apply(x1, self._packed.get_wino(self.weight), self.bias, d, norm.weight, norm.bias, G, norm.eps, act=act, residual=residual,
+                                   emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, want_wino=want, pinned=pinned)
+        if not want:
+            y._mf_wino_site = (self._wino_sites, key)
+        return y
 
     def forward_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst):
         """conv -> GroupNorm -> Swish -> + residual -> + emb in ONE launch (mf_conv2d_f16x2_gn_apply), or None when this convolution cannot
@@ -338,6 +410,13 @@ class BasicBlock(nn.Module):
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
                 raise RuntimeError("norm/act epilogue needs NHWC")
+            if CONV_PRECISION == 5 and WINOGRAD and WINO_TAIL and in_layout == L.LAYOUT_NHWC:
+                nm = self.norm
+                x1 = _split(x)[0]
+                y = self.conv.forward_wino_gn_apply(x, nm, int(self.has_act), residual, emb, emb_stride, out_fp32,
+                                                    nm.bound_const(x1.shape[1] * x1.shape[2] * (self.conv.out_ch // nm.num_groups)))
+                if y is not None:
+                    return y
             if f16x2_mode() and in_layout == L.LAYOUT_NHWC and not K.Rendezvous.disabled:
                 # one launch for conv + GroupNorm + Swish + residual + embedding where the plan allows it (conv_f16x2.h: FuseP)
                 nm = self.norm
@@ -414,7 +493,7 @@ class BasicResBlock(nn.Module):
         x1, x2 = _split(x)
         n, h, w, c1 = x1.shape
         c2 = 0 if x2 is None else x2.shape[-1]
-        key = (n, h, w, c1, c2)
+        key = (n, h, w, c1, c2, WINOGRAD)
         if key in self._group:
             return self._group[key]
         ent = None
@@ -422,7 +501,7 @@ class BasicResBlock(nn.Module):
         G = nm.num_groups
         if c1 + c2 == c3.in_ch and not c3.upsample and G <= 256:
             da = K.make_conv_desc(n, h, w, c1, c2, c3.out_ch, c3.k, c3.stride, c3.pad, 0, precision=5)
-            if K.conv_f16x2_ok(da):
+            if K.conv_f16x2_ok(da) and not wino_wanted(da):   # (a 3x3 on its Winograd form is three launches of its own: no shared launch)
                 pa = K.pin_conv_plan(da)
                 parts = K.conv_gn_parts(da, G)
                 # guest tiles of the 8-wave hosts: the one whose grid is closest to one workgroup per CU first (profiles/r04_conv_sweep_planner_vs_best.txt)

@@ -15,7 +15,7 @@ CSRC = HERE / "csrc"
 OBJ = CSRC / "build"
 LIB = HERE / "libmedfusion_hip.so"
 SOURCES = ["api.hip", "conv.hip", "conv_f16x2.hip", "groupnorm.hip", "small_ops.hip", "sched_noise.hip", "attention.hip", "edge_ops.hip"]
-HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_f16x2_body.inc", "conv_f16x2_halo.h", "conv_f16x2_halo_body.inc", "conv_f16x2_group.h", "conv_f16x2_epilogue.inc", "conv_plan.h", "split_f16.h", "conv_plan_table.inc"]
+HEADERS = ["common.h", "gn_partial.h", "conv_igemm.h", "conv_f16x2.h", "conv_f16x2_body.inc", "conv_f16x2_halo.h", "conv_f16x2_halo_body.inc", "conv_f16x2_group.h", "conv_f16x2_epilogue.inc", "conv_plan.h", "split_f16.h", "conv_plan_table.inc", "winograd.h", "conv_f16x2_wino.inc", "wino_plan_table.inc"]
 # -packed-fp32-ops for conv_f16x2.hip.  gfx950 erratum, root-caused in round 3 (profiles/r03_pk_repro.txt, scripts/pk_repro_min.hip): a packed
 # fp32 instruction whose LOW result takes the HIGH half of src1 ("v_pk_mul_f32 vD, vA, vB op_sel:[0,1]") reads that operand as 0.0 in lanes
 # 48..63 now and then, while the other wave of the SIMD issues MFMAs and LDS reads return -- exactly what a co-resident conv workgroup does.
@@ -107,7 +107,7 @@ def conv_source_stamp() -> str:
     import hashlib
     h = hashlib.sha256()
     for name in ("conv_f16x2.h", "conv_f16x2_body.inc", "conv_f16x2.hip", "conv_f16x2_epilogue.inc", "conv_f16x2_halo.h", "conv_f16x2_halo_body.inc",
-                 "conv_f16x2_group.h", "conv_plan_table.inc", "split_f16.h"):
+                 "conv_f16x2_group.h", "conv_plan_table.inc", "split_f16.h", "winograd.h", "conv_f16x2_wino.inc", "wino_plan_table.inc"):
         h.update(name.encode())
         h.update((CSRC / name).read_bytes())
     h.update(" ".join(CFLAGS + EXTRA_CFLAGS.get("conv_f16x2.hip", [])).encode())

@@ -70,17 +70,18 @@ static hipEvent_t get_event() {
 
 static thread_local ProfScope* g_scope = nullptr;   // the innermost timing scope of the calling thread
 
-ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s), launches(0) {
+ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s), launches(0), prev(nullptr) {
   if (!g_prof) return;
   std::lock_guard<std::mutex> lk(g_mu);
   ProfRec r{family, get_event(), get_event(), flops, bytes, exec_flops < 0 ? flops : exec_flops};
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
+  prev = g_scope;   // (scopes may nest: the enclosing one takes over again when this one ends -- ADVICE r04)
   g_scope = this;
 }
 ProfScope::~ProfScope() {
   if (idx < 0) return;
-  if (g_scope == this) g_scope = nullptr;
+  if (g_scope == this) g_scope = prev;
   if (launches == 0) {   // a scope without a launch (an entry point that returned early): both events recorded here so that the query finds them
     std::lock_guard<std::mutex> lk(g_mu);
     (void)hipEventRecord(g_recs[idx].a, stream);
@@ -237,7 +238,7 @@ int mf_cmdlist_free(void* list) {
 
 const char* mf_prof_family_name(int f) {
   static const char* names[MF_FAM_COUNT] = {"conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply",
-                                            "linear", "sched", "noise", "attention", "misc", "conv_gn_fused"};
+                                            "linear", "sched", "noise", "attention", "misc", "conv_gn_fused", "wino_xform"};
   return (f >= 0 && f < MF_FAM_COUNT) ? names[f] : "?";
 }
 

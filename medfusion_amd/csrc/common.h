@@ -25,6 +25,7 @@ struct ProfScope {
   int idx;
   hipStream_t stream;
   int launches;   // launches issued inside this scope so far
+  ProfScope* prev;   // the enclosing scope of the calling thread (restored by the destructor)
 };
 bool prof_on();
 // Timing of a scope (round 4): its FIRST launch goes out through hipExtLaunchKernel with the scope's two events as the dispatch's own start / stop

@@ -90,6 +90,7 @@ struct ConvP2 {
   long slab;
   unsigned bytes1, bytes2, bytesw;
   int subpix, hw_src;
+  int wphase_rows;       // > 0: rows [k wphase_rows, (k + 1) wphase_rows) of the GEMM use weight slab k (the component GEMMs of the Winograd form, winograd.h)
   double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1, or tree)
   int gn_groups, gn_parts, gn_cpg;
   // split-K reduced INSIDE the launch (tree != 0, splitk a power of two): the partial tiles meet pairwise, level by level; at every level

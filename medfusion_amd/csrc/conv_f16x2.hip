@@ -9,6 +9,7 @@
 #include "conv_f16x2.h"
 #include "conv_f16x2_halo.h"
 #include "conv_f16x2_group.h"
+#include "winograd.h"
 
 using namespace mf;
 
@@ -87,7 +88,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   // offsets); nearest-x2 only in its sub-pixel form
   pl->ok = d->in_layout == MF_LAYOUT_NHWC && d->out_layout == MF_LAYOUT_NHWC && d->C1 % 32 == 0 && d->C2 % 32 == 0 && d->Cout % 64 == 0 &&
            d->upsample != 1 && d->tile_hint >= 0 && (double)d->N * d->Hin * d->Win * (d->C1 > d->C2 ? d->C1 : d->C2) * 4.0 < 4294967040.0 &&
-           (double)d->Cout * pl->K * 4.0 * (d->upsample == 2 ? 4 : 1) < 4294967040.0;
+           (double)d->Cout * pl->K * 4.0 * (d->upsample == 2 ? 4 : d->upsample == 3 ? 16 : 1) < 4294967040.0;
   if (!pl->ok) return MF_OK;
   // Choice of (tile, split-K): the exact entry of the sweep table for the shapes of the published models (conv_plan_table.inc, generated
   // by scripts/conv_sweep.py --emit-table on MI355X), else a cost model fitted to the same sweeps (microseconds):
@@ -95,7 +96,10 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
   //   main loop                     ceil(workgroups / resident slots) * iterations * t_it(tile)
   //   split-K                       3 per level of the in-launch tree (power-of-two splits), else reducer 4 + (sk + 1) * output bytes / 3.5 TB/s
   const long out_bytes = (long)pl->M * d->Cout * 4;
-  auto valid = [&](const Tile2& k) { return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0) && halo_fits(d, k); };
+  // (upsample == 3, the component GEMMs of the Winograd form: a tile lies inside one component = N / 16 pseudo-samples of hw_src rows)
+  auto valid = [&](const Tile2& k) {
+    return d->Cout % k.BN == 0 && (d->upsample != 2 || hw_src % k.BM == 0) && (d->upsample != 3 || ((long)(d->N / 16) * hw_src) % k.BM == 0) && halo_fits(d, k);
+  };
   auto sk_ok = [&](int sk) { return sk >= 1 && sk <= pl->cgroups; };
   auto chain_ok = [&](int sk) { return (long)cdiv(pl->cgroups, sk) * pl->taps <= 96; };  // the matrix core adds with truncation: one chain <= 96 chunks
   const Tile2* c = nullptr;   // fixed by the hint or the table, else chosen by the model
@@ -104,6 +108,7 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     for (const auto& k : kTiles2) if (k.id == d->tile_hint) c = &k;
     MF_REQUIRE(c && d->Cout % c->BN == 0, MF_EINVAL, "conv(f16x2): bad tile_hint %d for Cout %d", d->tile_hint, d->Cout);
     if (d->upsample == 2 && hw_src % c->BM) { pl->ok = false; return MF_OK; }
+    if (d->upsample == 3 && ((long)(d->N / 16) * hw_src) % c->BM) { pl->ok = false; return MF_OK; }
     if (!halo_fits(d, *c)) { pl->ok = false; return MF_OK; }
   } else {
     {
@@ -491,8 +496,9 @@ int mf_conv2d_f16x2_gn_apply(const void* x1s, const void* x2s, const void* ws, c
 struct Prep { mfc2::ConvP2 p; Plan2 pl; bool tree; double flops, bytes; int terms; };
 static int conv_f16x2_prepare(const void* x1s, const void* x2s, const void* ws, const float* bias, float* y, const float* x1_bound, const float* x2_bound,
                               float w_bound, float* y_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G,
-                              const MfGnFuse* fz, const MfConvDesc* d, const PairsOut* po, Prep* out) {
+                              const MfGnFuse* fz, const MfConvDesc* d, const PairsOut* po, Prep* out, bool wino_gemm = false) {
   MF_REQUIRE(d && pair_precision(d->precision), MF_EINVAL, "conv(f16x2): desc.precision must be MF_CONV_FP32_F16X2 (or the opt-in MF_CONV_F16)");
+  MF_REQUIRE((d->upsample == 3) == wino_gemm, MF_EINVAL, "conv(f16x2): upsample = 3 is internal to mf_conv2d_wino_f16x2");
   Plan2& pl = out->pl;
   mfc2::ConvP2& p = out->p;
   int rc = make_plan2(d, &pl);
@@ -516,7 +522,8 @@ static int conv_f16x2_prepare(const void* x1s, const void* x2s, const void* ws, 
   p.slab = (long)pl.M * d->Cout;
   p.bytes1 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C1);
   p.bytes2 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C2);
-  p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1));
+  p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : wino_gemm ? 16 : 1));
+  p.wphase_rows = wino_gemm ? (d->N / 16) * d->Hin * d->Win : 0;
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
 #if MFC2_HZ & (256 | 512)
@@ -640,5 +647,7 @@ int mf_conv2d_f16x2_group(const MfConvF16x2Call* a, const MfConvF16x2Call* b, vo
   if (rc == -1) { set_error("conv_group: no tile pair (%d, %d)", qa.pl.t.id, qb.pl.t.id); rc = MF_EINVAL; }
   return rc;
 }
+
+#include "conv_f16x2_wino.inc"
 
 }  // extern "C"

@@ -22,12 +22,14 @@ inline int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
-  MF_REQUIRE(d->upsample >= 0 && d->upsample <= 2, MF_EINVAL, "conv: upsample flag");
+  // (upsample == 3 is INTERNAL: the component GEMMs of the Winograd form, built by mf_conv2d_wino_f16x2 itself -- conv_f16x2.hip)
+  MF_REQUIRE(d->upsample >= 0 && (d->upsample <= 2 || (d->upsample == 3 && d->precision == MF_CONV_FP32_F16X2 && d->KH == 1 && d->N % 16 == 0)), MF_EINVAL,
+             "conv: upsample flag");
   MF_REQUIRE(d->precision >= 0 && d->precision <= MF_CONV_F16, MF_EINVAL, "conv: precision flag %d", d->precision);
   MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");
   MF_REQUIRE(d->pad >= 0 && d->pad <= 1, MF_EUNSUPPORTED, "conv: pad %d unsupported", d->pad);
   MF_REQUIRE(!(d->in_layout == MF_LAYOUT_NCHW && d->C2 != 0), MF_EUNSUPPORTED, "conv: NCHW input with two sources");
-  const int up = d->upsample ? 1 : 0;
+  const int up = (d->upsample == 1 || d->upsample == 2) ? 1 : 0;
   pl->Heff = d->Hin << up;
   pl->Weff = d->Win << up;
   pl->Hout = (pl->Heff + 2 * d->pad - d->KH) / d->stride + 1;

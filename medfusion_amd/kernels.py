@@ -268,6 +268,8 @@ def drop_split(t: Optional[torch.Tensor]) -> None:
             t._mf_bound = None
         if getattr(t, "_mf_slots", None) is not None:
             t._mf_slots = None
+        if getattr(t, "_mf_wino", None) is not None:
+            t._mf_wino = t._mf_wino_bound = None
 
 
 def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
@@ -488,6 +490,132 @@ def conv2d_f16x2_pairs_out(x1: torch.Tensor, w_split, bias: Optional[torch.Tenso
     L.check(rc, "mf_conv2d_f16x2_pairs_out")
     out._mf_split, out._mf_bound = outs, ob
     _stamp(out)
+    return out
+
+
+# ----------------------------------------------------------------------------- Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolutions
+# The transform-domain mirror of an activation travels as attributes of the tensor, like the plain fp16-pair mirror: `t._mf_wino` (int32
+# [16, N, T, C]: V = B^T d B as fp16 pairs) and `t._mf_wino_bound` (float [16 N]).  Producers that write it themselves set both; a consumer that
+# finds neither runs the stand-alone input transform once (mf_wino_input_f16x2, from the plain pair mirror) and caches the result on the tensor.
+def wino_ok(d: L.MfConvDesc) -> bool:
+    return bool(L.load().mf_wino_ok(C.byref(d)))
+
+
+def wino_preferred(d: L.MfConvDesc) -> bool:
+    """did the Winograd form measure faster than the direct form for this exact shape (csrc/wino_plan_table.inc; MF_WINO=0/1/2)?"""
+    return bool(L.load().mf_wino_preferred(C.byref(d)))
+
+
+def wino_gn_parts(d: L.MfConvDesc, G: int) -> int:
+    return L.load().mf_wino_gn_parts(C.byref(d), G)
+
+
+def wino_pack_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 -> U = G g G^T as [16, Cout, 1, 1, Cin] fp32 (device, once at load)"""
+    _gpu(w_oihw)
+    w = w_oihw.contiguous()
+    co, ci, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    out = torch.empty((16, co, 1, 1, ci), dtype=torch.float32, device=w.device)
+    L.check(L.load().mf_wino_pack_weight_f32(w.data_ptr(), out.data_ptr(), co, ci, stream()), "mf_wino_pack_weight_f32")
+    return out
+
+
+def wino_input(x: torch.Tensor):
+    """(V as fp16 pairs [16, N, T, C], bounds [16 N]) of the NHWC activation x, cached on x.  A tensor whose producer could have written V
+    itself (conv2d_wino_gn_apply: `_mf_wino_site`) tells it so here: from its next call on that producer emits V with its output -- the
+    stand-alone transform below runs once per site (the eager warm-up iteration of a sampling loop), never in the recorded iteration."""
+    v = _fresh(x, "_mf_wino")
+    if v is None:
+        site = getattr(x, "_mf_wino_site", None)
+        if site is not None:
+            site[0][site[1]] = True
+        xs, xb = split_of(x), bound_of(x)
+        n, h, w, c = x.shape
+        v = torch.empty((16, n, (h // 2) * (w // 2), c), dtype=torch.int32, device=x.device)
+        vb = torch.empty((16 * n,), dtype=torch.float32, device=x.device)
+        L.check(L.load().mf_wino_input_f16x2(xs.data_ptr(), xb.data_ptr(), v.data_ptr(), vb.data_ptr(), n, h, w, c, stream()), "mf_wino_input_f16x2")
+        x._mf_wino, x._mf_wino_bound = v, vb
+        _stamp(x)
+    return v, x._mf_wino_bound
+
+
+def pin_wino_plan(d: L.MfConvDesc):
+    """(workspace bytes, sync words) of the Winograd form of `d`, computed once by callers that launch the same descriptor every iteration"""
+    lib = L.load()
+    return lib.mf_wino_workspace_bytes(C.byref(d)), lib.mf_wino_sync_words(C.byref(d))
+
+
+def conv2d_wino_f16x2(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, x2: Optional[torch.Tensor] = None,
+                      gn_groups: int = 0, gn_parts: int = 0, pinned=None):
+    """The 3x3 stride-1 convolution `d` in its Winograd form (mf_conv2d_wino_f16x2): u_split = split_weight_f16x2(wino_pack_weight(w)).
+    Returns y fp32 NHWC, or (y, partial [N, parts, G, 2]) when gn_groups > 0 (gn_parts = wino_gn_parts(d, G) > 0)."""
+    uh, umax = u_split
+    _gpu(x1, x2, uh, bias)
+    lib = L.load()
+    v1, b1 = wino_input(x1)
+    v2, b2 = wino_input(x2) if x2 is not None else (None, None)
+    dev = x1.device
+    out = torch.empty((d.N, d.Hin, d.Win, d.Cout), dtype=torch.float32, device=dev)
+    partial = torch.empty((d.N, gn_parts, gn_groups, 2), dtype=torch.float64, device=dev) if gn_groups else None
+    need, words = pinned if pinned is not None else pin_wino_plan(d)
+    ws = Workspace.get(need, dev)
+    sync = SyncWords.get(words, dev) if words else None
+    rc = lib.mf_conv2d_wino_f16x2(v1.data_ptr(), _ptr(v2), uh.data_ptr(), _ptr(bias), out.data_ptr(), b1.data_ptr(), _ptr(b2), umax, ws.data_ptr(), need,
+                                  _ptr(sync), _ptr(partial), gn_groups, C.byref(d), stream())
+    L.check(rc, "mf_conv2d_wino_f16x2")
+    return (out, partial) if gn_groups else out
+
+
+def wino_tail_ok(d: L.MfConvDesc, G: int) -> bool:
+    return bool(L.load().mf_wino_tail_ok(C.byref(d), G))
+
+
+def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, gamma, beta, G: int, eps: float, act: int = 1,
+                         residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
+                         x2: Optional[torch.Tensor] = None, bconst: float = 0.0, out_fp32: bool = True, want_wino: bool = False, pinned=None) -> torch.Tensor:
+    """Winograd conv -> GroupNorm -> Swish -> (+ residual) -> (+ emb) (-> the input transform of the next Winograd convolution) in two launches
+    (mf_conv2d_wino_gn_apply_f16x2): the component GEMM and one tail.  Returns the result with its fp16-pair mirror and bound attached (out_fp32 =
+    False: pairs only, like gn_apply) and, with want_wino, its transform-domain mirror as well."""
+    uh, umax = u_split
+    _gpu(x1, x2, uh, bias, gamma, beta, residual, emb)
+    lib = L.load()
+    v1, b1 = wino_input(x1)
+    v2, b2 = wino_input(x2) if x2 is not None else (None, None)
+    n, h, w, c = d.N, d.Hin, d.Win, d.Cout
+    dev = x1.device
+    res_pairs = rb = rslots = eb = None
+    if residual is not None:
+        if pairs_only(residual):
+            res_pairs, rb = residual._mf_split, residual._mf_bound
+        elif _fresh(residual, "_mf_bound") is None and _fresh(residual, "_mf_slots") is not None:
+            rslots = residual._mf_slots
+        else:
+            rb = bound_of(residual)
+    if emb is not None:
+        eb = _fresh(emb, "_mf_bound")
+        if eb is None:
+            eb = maxabs_rows(emb.contiguous())
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)
+    outs = torch.empty((n, h, w, c), dtype=torch.int32, device=dev)
+    ob = torch.empty((n,), dtype=torch.float32, device=dev)
+    ov = torch.empty((16, n, (h // 2) * (w // 2), c), dtype=torch.int32, device=dev) if want_wino else None
+    ovb = torch.empty((16 * n,), dtype=torch.float32, device=dev) if want_wino else None
+    need, words = pinned if pinned is not None else pin_wino_plan(d)
+    ws = Workspace.get(need, dev)
+    sync = SyncWords.get(words, dev) if words else None
+    t = L.MfWinoTail(_ptr(gamma), _ptr(beta), None if res_pairs is not None else _ptr(residual), _ptr(res_pairs), _ptr(rb), _ptr(rslots), _ptr(emb), _ptr(eb),
+                     out.data_ptr() if out_fp32 else None, outs.data_ptr(), ob.data_ptr(), _ptr(ov), _ptr(ovb), int(emb_stride),
+                     0 if rslots is None else rslots.shape[1], int(act), float(bconst), float(eps))
+    rc = lib.mf_conv2d_wino_gn_apply_f16x2(v1.data_ptr(), _ptr(v2), uh.data_ptr(), _ptr(bias), b1.data_ptr(), _ptr(b2), umax, ws.data_ptr(), need, _ptr(sync), G,
+                                           C.byref(t), C.byref(d), stream())
+    L.check(rc, "mf_conv2d_wino_gn_apply_f16x2")
+    out._mf_split, out._mf_bound = outs, ob
+    if want_wino:
+        out._mf_wino, out._mf_wino_bound = ov, ovb
+    _stamp(out)
+    if not out_fp32:
+        out._mf_pairs_only = True
     return out
 
 

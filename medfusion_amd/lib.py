@@ -40,6 +40,12 @@ class MfGnFuse(C.Structure):
                 ("emb_stride", C.c_int64), ("res_nslots", C.c_int32), ("act", C.c_int32), ("bconst", C.c_float), ("eps", C.c_float)]
 
 
+class MfWinoTail(C.Structure):
+    _fields_ = [("gamma", c_fp), ("beta", c_fp), ("residual", c_fp), ("residual_pairs", c_fp), ("res_bound", c_fp), ("res_bound_slots", c_fp),
+                ("emb", c_fp), ("emb_bound", c_fp), ("out", c_fp), ("out_split", c_fp), ("out_bound", c_fp), ("out_wino", c_fp), ("wino_bound", c_fp),
+                ("emb_stride", C.c_int64), ("res_nslots", C.c_int32), ("act", C.c_int32), ("bconst", C.c_float), ("eps", C.c_float)]
+
+
 class MfConvF16x2Call(C.Structure):
     """the arguments of one mf_conv2d_f16x2 call (mf_conv2d_f16x2_group takes two)"""
     _fields_ = [("x1s", c_fp), ("x2s", c_fp), ("ws", c_fp), ("bias", c_fp), ("y", c_fp), ("x1_bound", c_fp), ("x2_bound", c_fp), ("w_bound", C.c_float),
@@ -48,7 +54,7 @@ class MfConvF16x2Call(C.Structure):
 
 
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
-FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc", "conv_gn_fused")
+FAMILIES = ("conv_igemm", "conv_direct", "splitk_reduce", "gn_stats", "gn_apply", "linear", "sched", "noise", "attention", "misc", "conv_gn_fused", "wino_xform")
 
 _I, _I64, _F, _SZ, _U64 = C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 _SIGS = {
@@ -73,6 +79,17 @@ _SIGS = {
     "mf_conv2d_f16x2_gn_apply": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfGnFuse), C.POINTER(MfConvDesc), c_fp]),
     "mf_conv2d_f16x2_group_ok": (_I, [C.POINTER(MfConvDesc), _I, C.POINTER(MfConvDesc), _I]),
     "mf_conv2d_f16x2_group": (_I, [C.POINTER(MfConvF16x2Call), C.POINTER(MfConvF16x2Call), c_fp]),
+    "mf_wino_ok": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_wino_preferred": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_wino_pack_weight_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),
+    "mf_wino_input_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_wino_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),
+    "mf_wino_sync_words": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_wino_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_wino_plan_query": (_I, [C.POINTER(MfConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_conv2d_wino_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
+    "mf_wino_tail_ok": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_conv2d_wino_gn_apply_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, _I, C.POINTER(MfWinoTail), C.POINTER(MfConvDesc), c_fp]),
     "mf_maxabs_rows_slots": (_I, [_I64]),
     "mf_maxabs_rows_f32": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
     "mf_bound_finalize_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Winograd F(2x2, 3x3) against the direct form, per 3x3 stride-1 shape of the published UNet, as the ResBlocks run them (device time by
+command-list replay; cold weights: a timed sequence cycles through --cold-mb of weight copies, as the denoise loop does with its 777 MB):
+  direct : mf_conv2d_f16x2 (planner's plan, GroupNorm records from its epilogue) + mf_gn_apply_from_partials_pairs_f32 (Swish, residual, fp16-pair output)
+  wino   : mf_conv2d_wino_gn_apply_f16x2 = component GEMM + ONE tail launch (output transform, GroupNorm, Swish, residual, fp16-pair output AND the
+           transform-domain output for the next convolution); its own input arrives transformed (written by the previous tail) -- the stand-alone
+           input transform is timed beside it (`in`), it runs only behind down- / up-sampling
+Prints one line per shape, and writes --json: [N, H, W, Cin, Cout, tile, split-K] of the shapes where wino beats direct by > 2 %."""
+import argparse, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import torch
+import torch.nn.functional as F
+from medfusion_amd import kernels as K, lib as L
+from _devtime import device_us
+from conv_sweep import unet_shapes
+
+TILES = {31: (128, 256), 32: (256, 128), 33: (128, 128), 34: (128, 128), 35: (256, 64), 36: (128, 64), 37: (64, 256), 51: (128, 128), 52: (128, 128),
+         53: (64, 128), 54: (128, 64)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--latent", type=int, default=32)
+    ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--json", default="")
+    ap.add_argument("--tiles", action="store_true", help="also search the component GEMM's (tile, split-K); default: the planner's choice")
+    ap.add_argument("--cold-mb", type=int, default=1200, help="MB of distinct weight copies a timed sequence cycles through")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lib = L.load()
+    f = args.latent // 32
+    seen, table = set(), []
+    tot = {"direct": 0.0, "wino": 0.0, "best": 0.0}
+    G = 32
+    print(f"# B = {args.batch}, latent {args.latent}: conv + GroupNorm + Swish + residual, us per launch sequence")
+    print(f"{'shape':22s} {'GF':>6s} | direct: conv (plan) + apply = total | wino: GEMM+tail (tile,sk) [stand-alone input transform] | gain | err vs fp64 chain: direct, wino")
+    for name, n, h, w_, c1, c2, co, k, st, ups, cnt in unet_shapes(args.batch):
+        h, w_ = h * f, w_ * f
+        if k != 3 or st != 1 or ups or (args.only and args.only not in name):
+            continue
+        key = (n, h, w_, c1 + c2, co)
+        cin = c1 + c2
+        x1 = torch.randn((n, h, w_, c1), generator=g).to(dev)
+        x2 = torch.randn((n, h, w_, c2), generator=g).to(dev) if c2 else None
+        b = torch.randn((co,), generator=g).to(dev)
+        gamma, beta = (1.0 + 0.2 * torch.randn((co,), generator=g)).to(dev), (0.1 * torch.randn((co,), generator=g)).to(dev)
+        res = torch.randn((n, h, w_, co), generator=g).to(dev)
+        K.split_of(res)
+        res._mf_pairs_only = True          # (a block input that exists as fp16 pairs only, like the output of the previous tail / apply pass)
+        bconst = float(gamma.abs().max()) * (h * w_ * (co // G)) ** 0.5 + float(beta.abs().max())
+        wbytes = co * cin * 9 * 4
+        ncopy = max(2, -(-args.cold_mb * 1_000_000 // wbytes))
+        w0 = torch.randn((co, cin, 3, 3), generator=g) * (1.0 / (cin * 9) ** 0.5)
+        whs = [K.split_weight_f16x2(K.pack_conv_weight(w0.to(dev))) for _ in range(ncopy)]
+        uhs = [K.split_weight_f16x2(K.wino_pack_weight(w0.to(dev))) for _ in range(-(-ncopy * 9 // 16))]
+        d0 = K.make_conv_desc(n, h, w_, c1, c2, co, 3, 1, 1, 0, precision=5)
+        plan = K.conv_plan(d0)
+        dd = K.make_conv_desc(n, h, w_, c1, c2, co, 3, 1, 1, 0, precision=5)   # (pin_conv_plan writes the plan into the descriptor's hints: d0 stays clean)
+        pin = K.pin_conv_plan(dd)
+        parts = K.conv_gn_parts(dd, G)
+        if not parts:
+            print(f"{name:22s} the direct form emits no GroupNorm records here: skipped")
+            continue
+
+        def direct_conv():
+            return [K.conv2d_f16x2(x1, wh, b, dd, x2=x2, gn_groups=G, gn_parts=parts, pinned=pin) for wh in whs]
+
+        def direct():
+            outs = []
+            for wh in whs:
+                y, partial = K.conv2d_f16x2(x1, wh, b, dd, x2=x2, gn_groups=G, gn_parts=parts, pinned=pin)
+                outs.append(K.gn_apply(y, K.GnPartials(partial, parts, 1e-5), gamma, beta, G, 1, res, None, 0, split=True, bconst=bconst, out_fp32=False))
+            return outs
+        t_dconv = device_us(direct_conv, args.reps)[0] / len(whs)
+        t_direct = device_us(direct, args.reps)[0] / len(whs)
+        if not K.wino_tail_ok(d0, G):
+            print(f"{name:22s} not on the Winograd path")
+            continue
+        xs1, xb1 = K.split_of(x1), K.bound_of(x1)
+        v1 = torch.empty((16, n, (h // 2) * (w_ // 2), c1), dtype=torch.int32, device=dev)
+        vb1 = torch.empty((16 * n,), dtype=torch.float32, device=dev)
+
+        def tin():
+            L.check(lib.mf_wino_input_f16x2(xs1.data_ptr(), xb1.data_ptr(), v1.data_ptr(), vb1.data_ptr(), n, h, w_, c1, K.stream()), "wino_input")
+            return v1
+        t_in = device_us(tin, args.reps)[0]
+        cands = [(0, 0)]
+        if args.tiles:
+            rows = n * (h // 2) * (w_ // 2)
+            cands += [(t, sk) for t, (bm, bn) in TILES.items() if rows % bm == 0 and co % bn == 0 for sk in (1, 2) if cin // 32 // sk >= 8 or sk == 1]
+        best, allres = None, []
+        for tile, sk in cands:
+            d = K.make_conv_desc(n, h, w_, c1, c2, co, 3, 1, 1, 0, tile_hint=tile, splitk_hint=sk, precision=5)
+            if not K.wino_ok(d):
+                continue
+            wpin = K.pin_wino_plan(d)
+
+            def wino():
+                return [K.conv2d_wino_gn_apply(x1, uh, b, d, gamma, beta, G, 1e-5, act=1, residual=res, x2=x2, bconst=bconst, out_fp32=False, want_wino=True, pinned=wpin)
+                        for uh in uhs]
+            t = device_us(wino, args.reps)[0] / len(uhs)
+            allres.append((t, tile, sk))
+            if best is None or t < best[0]:
+                best = (t, tile, sk)
+        t_w, tile, sk = best
+        if t_w > 0.99 * allres[0][0]:     # keep the planner's own choice unless the search beats it by more than the noise
+            t_w, tile, sk = allres[0]
+        tq, kq = L.C.c_int32(), L.C.c_int32()
+        dq = K.make_conv_desc(n, h, w_, c1, c2, co, 3, 1, 1, 0, tile_hint=tile, splitk_hint=sk, precision=5)
+        lib.mf_wino_plan_query(L.C.byref(dq), L.C.byref(tq), L.C.byref(kq))
+        # accuracy of the whole chain on sample 0 against fp64 (CPU)
+        xin = x1[:1] if x2 is None else torch.cat([x1[:1], x2[:1]], -1)
+        y64 = F.conv2d(xin.cpu().double().permute(0, 3, 1, 2), w0.double(), b.cpu().double(), padding=1)
+        t64 = F.group_norm(y64, G, gamma.cpu().double(), beta.cpu().double(), 1e-5)
+        ref = (t64 * torch.sigmoid(t64)).permute(0, 2, 3, 1) + res[:1].cpu().double()
+        yd, pd = K.conv2d_f16x2(x1, whs[0], b, dd, x2=x2, gn_groups=G, gn_parts=parts, pinned=pin)
+        od = K.gn_apply(yd, K.GnPartials(pd, parts, 1e-5), gamma, beta, G, 1, res, None, 0, split=True, bconst=bconst)[:1].cpu().double()
+        ow = K.conv2d_wino_gn_apply(x1, uhs[0], b, dq, gamma, beta, G, 1e-5, act=1, residual=res, x2=x2, bconst=bconst, out_fp32=True)[:1].cpu().double()
+        ed, ew = float((od - ref).abs().max() / ref.abs().max()), float((ow - ref).abs().max() / ref.abs().max())
+        gf = 2.0 * n * h * w_ * co * 9 * cin / 1e9
+        gain = t_direct / t_w - 1.0
+        print(f"{name:22s} {gf:6.2f} | {t_dconv:6.1f} ({plan[0]},{plan[1]}) + {t_direct - t_dconv:5.1f} = {t_direct:6.1f} | {t_w:6.1f} ({tq.value},{kq.value}) [{t_in * cin / c1:5.1f}] | "
+              f"{100 * gain:+6.1f} % | {ed:.1e} {ew:.1e}", flush=True)
+        if args.tiles:
+            print("    GEMM + tail, us by (tile, split-K): " + " ".join(f"{t}/{k}:{us:.1f}" for us, t, k in sorted(allres)[:10]), flush=True)
+        tot["direct"] += t_direct * cnt
+        tot["wino"] += t_w * cnt
+        tot["best"] += min(t_direct, t_w) * cnt
+        if gain > 0.02 and key not in seen:
+            seen.add(key)
+            table.append([n, h, w_, cin, co, tile, sk])
+    print(f"TOTAL per UNet evaluation (3x3 stride-1 convolutions with their GroupNorm tails): direct {tot['direct']:.0f} us; all Winograd {tot['wino']:.0f} us; "
+          f"per-shape best {tot['best']:.0f} us")
+    if args.json:
+        Path(args.json).write_text(json.dumps(table))
+        print(f"wrote {len(table)} shapes to {args.json}")
+
+
+if __name__ == "__main__":
+    main()

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
-    assert lib.mf_version() == 220
+    assert lib.mf_version() == 230
     assert lib.mf_prof_family_name(0) == b"conv_igemm"
 
 
@@ -31,6 +31,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(L.MfSchedArgs) == 8 * 6 + 8 + 8 * 5 + 4 * 4 + 8  # 6 ptr, i64, 5 ptr, 3 i32 + f32, i64
     assert C.sizeof(L.MfGnFuse) == 8 * 13 + 8 + 4 * 4                   # 13 ptr, i64, 2 i32 + 2 f32
     assert C.sizeof(L.MfConvF16x2Call) == 8 * 7 + 8 + 8 * 5 + 8 + 8           # 7 ptr, f32 (+ pad), 5 ptr / size_t, i32 (+ pad), ptr
+    assert C.sizeof(L.MfWinoTail) == 8 * 13 + 8 + 4 * 4                 # 13 ptr, i64, 2 i32 + 2 f32
 
 
 def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
@@ -43,7 +44,8 @@ def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
     gcc = shutil.which("gcc")
     if gcc is None:
         pytest.skip("no gcc")
-    structs = {"MfConvDesc": L.MfConvDesc, "MfSchedStep": L.MfSchedStep, "MfSchedArgs": L.MfSchedArgs, "MfGnFuse": L.MfGnFuse, "MfConvF16x2Call": L.MfConvF16x2Call}
+    structs = {"MfConvDesc": L.MfConvDesc, "MfSchedStep": L.MfSchedStep, "MfSchedArgs": L.MfSchedArgs, "MfGnFuse": L.MfGnFuse, "MfConvF16x2Call": L.MfConvF16x2Call,
+               "MfWinoTail": L.MfWinoTail}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "medfusion_hip.h"', 'int main(void) {']
     for name, cls in structs.items():
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
@@ -219,5 +221,5 @@ int main(void) {
     ver, rc, ok, tile, sk = map(int, out[0].split())
     from medfusion_amd import kernels as K
     want = K.conv_plan(K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5))
-    assert (ver, rc, ok) == (220, 0, 1) and (tile, sk) == want
+    assert (ver, rc, ok) == (230, 0, 1) and (tile, sk) == want
     assert out[1].startswith("0|") and "unsupported" in out[1]

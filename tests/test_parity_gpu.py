@@ -43,14 +43,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[5, 1, 0], ids=["f16x2", "split3", "fp32mfma"], autouse=True)
+@pytest.fixture(params=[(5, 1), (5, 2), (1, 1), (0, 1)], ids=["f16x2", "f16x2_winograd_everywhere", "split3", "fp32mfma"], autouse=True)
 def conv_precision(request):
-    """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3_W3, MF_CONV_FP32), same tolerances"""
+    """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3_W3, MF_CONV_FP32), same tolerances;
+    the default arithmetic twice: as shipped (the Winograd form on the shapes of csrc/wino_plan_table.inc) and with that form wherever the
+    library can run it (blocks.WINOGRAD = 2)"""
     from medfusion_amd import blocks as BLK
-    old = BLK.CONV_PRECISION
-    BLK.CONV_PRECISION = request.param
-    yield request.param
-    BLK.CONV_PRECISION = old
+    old = BLK.CONV_PRECISION, BLK.WINOGRAD
+    BLK.CONV_PRECISION, BLK.WINOGRAD = request.param
+    yield request.param[0]
+    BLK.CONV_PRECISION, BLK.WINOGRAD = old
 
 
 def nhwc(x, dev):
