@@ -47,13 +47,15 @@ ARITH = {
     4: dict(kernel="conv_igemm_kernel<..., MODE 5>", pmc_match=("conv_igemm_kernel<", ", 5, "), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),
-    5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN> (+ its halo form conv_halo_kernel and conv_group_kernel: conv_res in the grid of its ResBlock's 3x3)", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS,
+    5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN> (+ its halo form conv_halo_kernel and conv_group_kernel: conv_res in the grid of its ResBlock's 3x3; the same kernel runs the component GEMMs of the Winograd form)", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS,
             dtype="f32 (emulated: fp16 pairs, 23-bit operands)",
             text="fp32 EMULATED through PAIRS of fp16: every operand stored as hi + lo/2048 (23 of 24 significand bits, error <= one fp32 ulp, zero for 3 values "
                  "of 4), 3 product terms on v_mfma_f32_32x32x16_f16 (the lo*lo term is dropped), fp32 accumulate; both operands moved HBM->LDS by "
-                 "LDS-DMA.  Error vs an fp64 convolution: asserted < 3x the fp32-MFMA kernel's + 1e-6 on every test shape "
-                 "(tests/test_kernels_gpu.py::test_conv_f16x2), measured BELOW it on every shape of profiles/r02_split_accuracy.txt; not bit-width-equal "
-                 "to fp32 -- the exact-operand arithmetics are timed in the same run (other_conv_arithmetic)"),
+                 "LDS-DMA.  Error vs an fp64 convolution: < 3x the fp32-MFMA kernel's + 1e-6 (asserted on every test shape, "
+                 "tests/test_kernels_gpu.py::test_conv_f16x2), 0.4-2.1x measured (profiles/r02_split_accuracy.txt, profiles/r04_parity_measured.txt); not "
+                 "bit-width-equal to fp32 -- the exact-operand arithmetics are timed in the same run (other_conv_arithmetic).  Round 5: the 3x3 stride-1 "
+                 "convolutions of the 8 x 8 and 16 x 16 levels run in their Winograd F(2x2,3x3) form on this arithmetic (16 component GEMMs on the same "
+                 "kernel, 2.25x fewer matrix instructions; csrc/wino_plan_table.inc; error vs fp64 at or below the direct form's, profiles/r05_winograd_ab.txt)"),
     6: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN, NST, 1>", pmc_match=("conv_f16x2_kernel<", ", 1>"), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="f16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision on the LDS-DMA kernel: conv operands rounded to fp16 (11 significant bits, per-sample power-of-two scales), one MFMA "
@@ -164,9 +166,7 @@ def cpu_baseline(classes):
         t0 = time.perf_counter()
         unet(z, t1)
         t_b1 = time.perf_counter() - t0
-        all_threads = {"threads": 256, "unet_b1_seconds": 51.0, "unet_b1_seconds_at_32_threads": 0.198, "slowdown_vs_baseline_threads": 257.5,
-                       "measured": "round 4 on the GPU box's EPYC 9575F (profiles/r04_baseline_bench_cfg2.json); re-measure with --cpu-all-threads (~100 s)",
-                       "what": "one published-UNet forward at B=1 on all 256 logical CPUs vs on 32: the reason cpu_baseline.cores is 32, not os.cpu_count()"}
+        all_threads = None   # (measured only with --cpu-all-threads, ~100 s: round 4 on this host class gave 51.0 s at 256 threads vs 0.198 s at 32 -- profiles/r04_baseline_bench_cfg2.json)
         if ncpu > threads and MEASURE_ALL_THREADS:
             torch.set_num_threads(ncpu)
             unet(z, t1)
@@ -189,7 +189,7 @@ def cpu_baseline(classes):
     return {"value": round(ips, 5), "unit": "images/s", "cores": threads, "host_logical_cpus": ncpu, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle (CPU restatement of the reference, torch fp32, {threads} threads of {ncpu} logical CPUs): 3 UNet forwards at B=4 "
                       f"({t_unet:.3f} s each) + 1 VAE decode at B=1 ({t_dec:.3f} s), extrapolated to 150 iterations x 4 images",
-            "all_threads": all_threads,
+            "all_threads": all_threads, "unet_b1_seconds": round(t_b1, 4),
             "cfg1_full": {"value": round(2.0 / t_cfg1, 4), "unit": "images/s", "seconds": round(t_cfg1, 2),
                           "what": "BASELINE configs[0] run in full on the same threads: 2 unconditional 64x64 images (latent 8x8x8), 50 DDIM iterations + VAE "
                                   "decode, published architecture"}}
@@ -337,8 +337,23 @@ def main():
                          "how": "mf_mfma_rate_probe_f16 live on this device: v_mfma_f32_32x32x16_f16 from registers only, 4 chains per wave, 2 waves "
                                 "per SIMD, one workgroup per CU, 0.6 ms bursts, best of 3 (scripts/mfma_power_probe.hip, "
                                 "profiles/r02_mfma_power_probe.txt): the pipe is power-limited by the data it multiplies"}
+        # per kernel instantiation (name as rocprofv3 --kernel-trace prints it), so that every row can be recomputed from the committed
+        # profiles/*_kernel_stats.csv: launches, average duration, algorithmic and executed GFLOP per launch, executed fraction of the peak
+        inst = {}
+        for r in K.prof_rows("conv_igemm") + (K.prof_rows("conv_gn_fused") if "conv_gn_fused" in tab else []):
+            e = inst.setdefault(r["kernel"], dict(kernel=r["kernel"], launches=0, ms=0.0, flops=0.0, exec_flops=0.0, winograd_launches=0, winograd_ms=0.0))
+            e["launches"] += r["launches"]; e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec_flops"] += r["exec_flops"]
+            if r["variant"] == 1:
+                e["winograd_launches"] += r["launches"]; e["winograd_ms"] += r["ms"]
+        instantiations = [dict(kernel=e["kernel"], launches=int(e["launches"]), avg_us=round(e["ms"] / e["launches"] * 1e3, 2), total_ms=round(e["ms"], 3),
+                               algorithmic_gflop_per_launch=round(e["flops"] / e["launches"] / 1e9, 3), executed_gflop_per_launch=round(e["exec_flops"] / e["launches"] / 1e9, 3),
+                               algorithmic_tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1), executed_frac_of_peak=round(e["exec_flops"] / (e["ms"] * 1e-3) / 1e12 / ar["peak"], 4),
+                               winograd_component_gemm_launches=int(e["winograd_launches"]), winograd_ms=round(e["winograd_ms"], 3))
+                          for e in sorted(inst.values(), key=lambda e: -e["ms"])]
+        wino_ms = sum(e["winograd_ms"] for e in inst.values())
+        wino_n = sum(e["winograd_launches"] for e in inst.values())
         hbm = {}
-        for fam in ("gn_apply", "splitk_reduce", "gn_stats", "sched", "noise"):
+        for fam in ("gn_apply", "wino_xform", "splitk_reduce", "gn_stats", "sched", "noise"):
             if fam in tab and tab[fam][0] > 0:
                 hbm[fam] = {"ms": round(tab[fam][0], 3), "launches": int(tab[fam][1]), "algorithmic_GBps": round(tab[fam][3] / (tab[fam][0] * 1e-3) / 1e9, 1)}
         roof = {"bound": "mfma", "kernel": f"{ar['kernel']} -- {ar['text']}",
@@ -346,7 +361,15 @@ def main():
                 "mfma_sustained": sustained,
                 "frac_of_sustained_random_operands": None if sustained is None else round(exe / sustained["random_operands_tflops"], 4),
                 "frac_is": "EXECUTED matrix flops of the implicit-GEMM conv kernel / the dense MFMA peak of the pipe it runs on "
-                           f"({ar['terms']} matrix term(s) per product)",
+                           f"({ar['terms']} matrix term(s) per product; a convolution on its Winograd form executes 4/9 of its multiplications -- the "
+                           "form REMOVES work, so this fraction falls while algorithmic_tflops and images/s rise: frac_arithmetic_ceiling is the "
+                           "round-over-round figure)",
+                "winograd": {"component_gemm_launches": int(wino_n), "ms": round(wino_ms, 3), "share_of_conv_time": round(wino_ms / ms, 4),
+                             "tail_and_transform_ms": round(tab["wino_xform"][0], 3) if "wino_xform" in tab else 0.0,
+                             "what": "3x3 stride-1 convolutions of csrc/wino_plan_table.inc as 16 component GEMMs on the same kernel (algorithmic flops: the "
+                                     "convolution's own 2 M Cout 9 Cin; executed: 3 terms x 2 (4 M / 4) Cout Cin); their output transform + GroupNorm + Swish + "
+                                     "residual + next input transform is ONE tail launch each (family wino_xform, an HBM-bound pass: hbm_bound_passes)"},
+                "instantiations": instantiations,
                 "algorithmic_tflops": round(alg, 2),
                 "x_over_fp32_peak_algorithmic": round(alg / PEAK_FP32_TFLOPS, 4),   # (a ratio, not a roofline fraction: the work runs on the fp16 pipe)
                 "frac_arithmetic_ceiling": round(alg / (ar["peak"] / ar["terms"]), 4),
@@ -423,7 +446,11 @@ def main():
             # the oracle evaluations that were just timed, as the CHECKER of what was benchmarked (same seeded weights): one UNet forward at
             # B = 4 and one VAE decode through the product path on this device.  A number from a path that computes something else is no number
             # (round 4: a bound-propagation bug produced finite, constant images at full speed) -- bench.py fails loudly instead of printing it.
-            from tests.util import relerr, relerr_rows
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_medfusion_tests_util", ROOT / "tests" / "util.py")   # (by path: an installed top-level `tests` package must not shadow it)
+            tu = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(tu)
+            relerr, relerr_rows = tu.relerr, tu.relerr_rows
             with torch.no_grad():
                 g_unet = pipe.noise_estimator(CHECK["x"].to(dev), CHECK["t"].to(dev), None)[0]
                 g_dec = pipe.latent_embedder.decode(CHECK["z"].to(dev))

@@ -475,6 +475,13 @@ int mf_prof_query(int family, double* ms, int64_t* launches, double* flops, doub
 /* the same plus the flops the hardware EXECUTES for those launches (matrix terms per product x the MACs actually done) */
 int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, double* bytes, double* exec_flops);
 const char* mf_prof_family_name(int family);
+/* The same records grouped by KERNEL INSTANTIATION (ABI 230): `tag` identifies the instantiation -- for the fp16-pair convolution family its tile id
+ * (a grouped launch: 1000 + 100 host tile + guest tile; the single-term mode: + 100000) --, `variant` 1 marks the component GEMMs of the Winograd
+ * form (same kernel, same name in a profiler).  mf_prof_rows fills up to max_rows rows and returns how many; mf_prof_tag_name writes the kernel's
+ * name as rocprofv3 --kernel-trace prints it, so that a row can be checked against the committed kernel_stats.csv. */
+typedef struct MfProfRow { int32_t tag, variant; int64_t launches; double ms, flops, bytes, exec_flops; } MfProfRow;
+int mf_prof_rows(int family, MfProfRow* rows, int max_rows);
+int mf_prof_tag_name(int family, int tag, char* buf, int n);
 /* Measurement aid: what the fp16 matrix pipe SUSTAINS on this device for given operand data.  Launches `workgroups` x 512 threads running
  * nothing but v_mfma_f32_32x32x16_f16 from registers (4 independent chains per wave, `iters` instructions per chain; operands = the first
  * workgroups * 512 * 8 sixteen-byte groups of fp16 at `operands`, loaded once; `out`: workgroups * 512 floats) and reports the flops of the

@@ -49,6 +49,7 @@ struct ProfRec {
   int family;
   hipEvent_t a, b;
   double flops, bytes, exec_flops;
+  int tag, variant;
 };
 static bool g_prof = false;
 static std::mutex g_mu;
@@ -73,7 +74,7 @@ static thread_local ProfScope* g_scope = nullptr;   // the innermost timing scop
 ProfScope::ProfScope(int family, hipStream_t s, double flops, double bytes, double exec_flops) : idx(-1), stream(s), launches(0), prev(nullptr) {
   if (!g_prof) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  ProfRec r{family, get_event(), get_event(), flops, bytes, exec_flops < 0 ? flops : exec_flops};
+  ProfRec r{family, get_event(), get_event(), flops, bytes, exec_flops < 0 ? flops : exec_flops, 0, 0};
   g_recs.push_back(r);
   idx = (int)g_recs.size() - 1;
   prev = g_scope;   // (scopes may nest: the enclosing one takes over again when this one ends -- ADVICE r04)
@@ -87,6 +88,13 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(g_recs[idx].a, stream);
     (void)hipEventRecord(g_recs[idx].b, stream);
   }
+}
+
+void ProfScope::set_tag(int tag, int variant) {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_recs[idx].tag = tag;
+  g_recs[idx].variant = variant;
 }
 
 bool prof_launch(const void* func, dim3 grid, dim3 block, void** argv, size_t lds, hipStream_t s) {
@@ -189,6 +197,33 @@ int mf_prof_query2(int family, double* ms, int64_t* launches, double* flops, dou
   if (bytes) *bytes = by;
   if (exec_flops) *exec_flops = ex;
   return MF_OK;
+}
+
+int mf_prof_rows(int family, MfProfRow* rows, int max_rows) {
+  MF_REQUIRE(rows && max_rows > 0, MF_EINVAL, "mf_prof_rows: bad args");
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  for (auto& r : g_recs) {
+    if (r.family != family) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) {
+      set_error("mf_prof_rows: event sync failed");
+      return MF_ELAUNCH;
+    }
+    float dt = 0;
+    (void)hipEventElapsedTime(&dt, r.a, r.b);
+    int k = 0;
+    while (k < n && !(rows[k].tag == r.tag && rows[k].variant == r.variant)) ++k;
+    if (k == n) {
+      if (n == max_rows) continue;   // (more instantiations than the caller has room for: the rest is dropped, the family totals still hold)
+      rows[n++] = MfProfRow{r.tag, r.variant, 0, 0.0, 0.0, 0.0, 0.0};
+    }
+    rows[k].launches += 1;
+    rows[k].ms += dt;
+    rows[k].flops += r.flops;
+    rows[k].bytes += r.bytes;
+    rows[k].exec_flops += r.exec_flops;
+  }
+  return n;
 }
 
 /* ---- command lists: record the launches of one loop iteration, replay them from C (include/medfusion_hip.h) */

@@ -26,6 +26,7 @@ struct ProfScope {
   hipStream_t stream;
   int launches;   // launches issued inside this scope so far
   ProfScope* prev;   // the enclosing scope of the calling thread (restored by the destructor)
+  void set_tag(int tag, int variant = 0);   // which kernel instantiation the scope's launch is (mf_prof_rows groups by it); no-op when timing is off
 };
 bool prof_on();
 // Timing of a scope (round 4): its FIRST launch goes out through hipExtLaunchKernel with the scope's two events as the dispatch's own start / stop

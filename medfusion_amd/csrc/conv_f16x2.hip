@@ -576,6 +576,7 @@ static int conv_f16x2_impl(const void* x1s, const void* x2s, const void* ws, con
   {
     const int terms = q.terms;
     ProfScope ps(fz ? MF_FAM_CONV_GN_FUSED : MF_FAM_CONV_IGEMM, s, q.flops, q.bytes, 2.0 * pl.M * (double)d->Cout * pl.K * terms);
+    ps.set_tag(pl.t.id + (terms == 1 ? 100000 : 0));
     rc = dispatch_tile(pl.t.id, p, s, terms, 0);
     if (rc == -1) { set_error("conv(f16x2): no tile config %d", pl.t.id); rc = MF_EINVAL; }
   }
@@ -643,9 +644,38 @@ int mf_conv2d_f16x2_group(const MfConvF16x2Call* a, const MfConvF16x2Call* b, vo
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(MF_FAM_CONV_IGEMM, s, qa.flops + qb.flops, qa.bytes + qb.bytes,
                2.0 * 3.0 * (qa.pl.M * (double)a->d->Cout * qa.pl.K + qb.pl.M * (double)b->d->Cout * qb.pl.K));
+  ps.set_tag(1000 + 100 * qa.pl.t.id + qb.pl.t.id);
   rc = dispatch_group(qa.pl.t.id, qb.pl.t.id, qa.p, qb.p, s, 0);
   if (rc == -1) { set_error("conv_group: no tile pair (%d, %d)", qa.pl.t.id, qb.pl.t.id); rc = MF_EINVAL; }
   return rc;
+}
+
+int mf_prof_tag_name(int family, int tag, char* buf, int n) {
+  MF_REQUIRE(buf && n > 0, MF_EINVAL, "mf_prof_tag_name: bad args");
+  auto tile_of = [](int id) -> const Tile2* { for (const auto& k : kTiles2) if (k.id == id) return &k; return nullptr; };
+  auto tile_type = [&](int id, char* o, int m) {
+    const Tile2* t = tile_of(id);
+    if (!t) { snprintf(o, m, "?"); return; }
+    if (t->HG) snprintf(o, m, "mfc2::HaloTile<%d, %d, %d, %d, %d>", t->BM, t->BN, t->WM, t->WN, t->HG);
+    else snprintf(o, m, "mfc2::PlainTile<%d, %d, %d, %d, %d>", t->BM, t->BN, t->WM, t->WN, t->NST);
+  };
+  if ((family == MF_FAM_CONV_IGEMM || family == MF_FAM_CONV_GN_FUSED) && tag > 0) {
+    const int terms = tag >= 100000 ? 1 : 3, id = tag % 100000;
+    if (id >= 1000) {
+      char a[96], b[96];
+      tile_type((id - 1000) / 100, a, sizeof a);
+      tile_type((id - 1000) % 100, b, sizeof b);
+      snprintf(buf, n, "void mfc2::conv_group_kernel<%s, %s, 3>(mfc2::ConvP2, mfc2::ConvP2, int)", a, b);
+      return MF_OK;
+    }
+    if (const Tile2* t = tile_of(id)) {
+      if (t->HG) snprintf(buf, n, "void mfc2::conv_halo_kernel<%d, %d, %d, %d, %d, %d>(mfc2::ConvP2)", t->BM, t->BN, t->WM, t->WN, t->HG, terms);
+      else snprintf(buf, n, "void mfc2::conv_f16x2_kernel<%d, %d, %d, %d, %d, %d>(mfc2::ConvP2)", t->BM, t->BN, t->WM, t->WN, t->NST, terms);
+      return MF_OK;
+    }
+  }
+  snprintf(buf, n, "%s (tag %d)", mf_prof_family_name(family), tag);
+  return MF_OK;
 }
 
 #include "conv_f16x2_wino.inc"

@@ -1144,6 +1144,23 @@ class prof:
         return out
 
 
+def prof_rows(family: str):
+    """the records of `family` (a name of lib.FAMILIES) since prof() started, grouped by kernel instantiation:
+    [{kernel (as rocprofv3 prints it), variant, launches, ms, flops, bytes, exec_flops}]"""
+    lib = L.load()
+    fam = L.FAMILIES.index(family)
+    rows = (L.MfProfRow * 64)()
+    n = lib.mf_prof_rows(fam, rows, 64)
+    if n < 0:
+        L.check(n, "mf_prof_rows")
+    out = []
+    buf = C.create_string_buffer(256)
+    for r in rows[:n]:
+        lib.mf_prof_tag_name(fam, r.tag, buf, 256)
+        out.append(dict(kernel=buf.value.decode(), tag=r.tag, variant=r.variant, launches=r.launches, ms=r.ms, flops=r.flops, bytes=r.bytes, exec_flops=r.exec_flops))
+    return out
+
+
 def mfma_sustained_tflops(device, data: str = "random", iters: int = 4000, reps: int = 3) -> float:
     """TFLOP/s the fp16 matrix pipe sustains on `device` with nothing but MFMAs in flight (mf_mfma_rate_probe_f16), operands "random"
     (N(0,1) as fp16) or "zeros": the measured ceiling bench.py sets next to the nominal peak."""

@@ -46,6 +46,11 @@ class MfWinoTail(C.Structure):
                 ("emb_stride", C.c_int64), ("res_nslots", C.c_int32), ("act", C.c_int32), ("bconst", C.c_float), ("eps", C.c_float)]
 
 
+class MfProfRow(C.Structure):
+    _fields_ = [("tag", C.c_int32), ("variant", C.c_int32), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+                ("exec_flops", C.c_double)]
+
+
 class MfConvF16x2Call(C.Structure):
     """the arguments of one mf_conv2d_f16x2 call (mf_conv2d_f16x2_group takes two)"""
     _fields_ = [("x1s", c_fp), ("x2s", c_fp), ("ws", c_fp), ("bias", c_fp), ("y", c_fp), ("x1_bound", c_fp), ("x2_bound", c_fp), ("w_bound", C.c_float),
@@ -138,6 +143,8 @@ _SIGS = {
     "mf_prof_query": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mf_prof_query2": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mf_prof_family_name": (C.c_char_p, [_I]),
+    "mf_prof_rows": (_I, [_I, C.POINTER(MfProfRow), _I]),
+    "mf_prof_tag_name": (_I, [_I, _I, C.c_char_p, _I]),
     "mf_mfma_rate_probe_f16": (_I, [c_fp, c_fp, _I, _I, C.POINTER(C.c_double), c_fp]),
     "mf_cmdlist_begin": (_I, []),
     "mf_cmdlist_end": (_I, [C.POINTER(C.c_void_p)]),

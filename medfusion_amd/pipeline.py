@@ -190,9 +190,13 @@ class DiffusionPipeline(nn.Module):
     # ------------------------------------------------------------------ the loop
     @torch.no_grad()
     def denoise(self, x_t, steps=None, condition=None, use_ddim=True, noise: Optional[NoiseSource] = None, trace=None, decode=True, use_graph=None,
-                loop: Optional[str] = None, **kwargs):
+                loop: Optional[str] = None, progress_cb=None, **kwargs):
         """diffusion_pipeline.py:278-310.  kwargs: guidance_scale, un_cond, cold_diffusion (forwarded to forward()
-        by the reference); `eta` raises like the reference's forward() would (Q2)."""
+        by the reference); `eta` raises like the reference's forward() would (Q2).
+        progress_cb(done, total): the hook that stands where the reference drives `st.progress` and `tqdm` (diffusion_pipeline.py:289-291; SURVEY Q16:
+        no streamlit import here).  Called on the host after the iterations up to `done` have been ENQUEUED -- the loop never waits for the device;
+        a callback that wants finished iterations synchronises the stream itself.  The replayed loops (command list, graph) call it every
+        max(1, total // 20) iterations; the Python loop every iteration."""
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
         with torch.cuda.device(x_t.device):   # (see sample())
@@ -210,9 +214,10 @@ class DiffusionPipeline(nn.Module):
                                        "cannot be rewound: set MEDFUSION_FUSED_APPLY=0 when several processes share one GPU")
                 noise.draw_index = draws0
 
-            return K.with_fused_fallback(x_t.device, lambda: self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **dict(kwargs)), rewind)
+            return K.with_fused_fallback(x_t.device, lambda: self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, progress_cb,
+                                                                           **dict(kwargs)), rewind)
 
-    def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, **kwargs):
+    def _denoise(self, x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, progress_cb=None, **kwargs):
         K.SyncWords.reset(x_t.device)   # (the split-K counters of the convolutions: zero by invariant, re-zeroed once per loop for robustness)
         if "eta" in kwargs:
             raise TypeError("forward() got an unexpected keyword argument 'eta'")
@@ -280,11 +285,14 @@ class DiffusionPipeline(nn.Module):
                     x_t = K.rows_axpby(K.rows_axpby(x_0, a, x_T, c), None, n_ddim, sg)   # x0 sqrt(a') + c x_T + sigma noise
                 else:
                     x_t = x_prior
+                if progress_cb is not None:
+                    progress_cb(i + 1, len(rev))
             if decode and self.latent_embedder is not None:
                 x_t = self.latent_embedder.decode(x_t)
             return x_t
         if mode in ("graph", "cmdlist"):
-            self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=(mode == "cmdlist"))
+            self._denoise_graph(x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=(mode == "cmdlist"),
+                                progress_cb=progress_cb)
         else:
             t_all = torch.tensor(rev, dtype=torch.float32, device=dev).reshape(-1, 1).expand(-1, B).contiguous()  # t.expand(B) per iteration (Q7)
             n_post = torch.empty_like(x_t)
@@ -308,6 +316,8 @@ class DiffusionPipeline(nn.Module):
                 self_cond = x0 if self.use_self_conditioning else None  # only None-ness matters downstream (Q11)
                 if trace is not None:
                     trace.append((x0.clone(), x_t.clone()))
+                if progress_cb is not None:
+                    progress_cb(i + 1, len(rev))
         if decode and self.latent_embedder is not None:
             x_t = self.latent_embedder.decode(x_t)
         return x_t
@@ -326,7 +336,7 @@ class DiffusionPipeline(nn.Module):
         cc, cu = est.embedding_columns(condition if has_c else None, B, dev, tab), est.embedding_columns(un_cond if has_c else None, B, dev, tab)
         return (tab, cc, cu, torch.cat([cu, cc]))   # (the last: columns of the 2B-row classifier-free-guidance pair, un-guided rows first)
 
-    def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=False):
+    def _denoise_graph(self, x_t, rev, recs, table, condition, guidance_scale, un_cond, use_ddim, noise, objective, cmdlist=False, progress_cb=None):
         """The loop body as ONE captured hipGraph replayed `steps` times (BASELINE.json configs[3]) -- or, cmdlist=True, recorded by the
         library while it runs once and re-issued from C (mf_cmdlist_*: the native command list of the loop body).  Everything the
         reference reads on the host each iteration (t, alphas_cumprod[t], the t==0 test, the RNG state) is indexed by a
@@ -429,8 +439,10 @@ class DiffusionPipeline(nn.Module):
                         # torch itself put device work into the iteration (self-conditioning, an attention variant, ...): the recorded list
                         # is not the whole iteration -- drop it and run the remaining iterations through Python (same bits, host-bound)
                         self.last_cmdlist_launches = 0
-                        for _ in range(2, len(rev)):
+                        for k in range(2, len(rev)):
                             body()
+                            if progress_cb is not None:
+                                progress_cb(k + 1, len(rev))
                     elif len(rev) > 2:
                         left = len(rev) - 2
                         if self.time_cmdlist and left > 1:   # measurement aid (scripts/enqueue_time.py): the host cost of ONE replayed
@@ -440,7 +452,16 @@ class DiffusionPipeline(nn.Module):
                             L.check(lib.mf_cmdlist_replay(handle, 1, cur), "mf_cmdlist_replay")
                             self.last_cmdlist_host_ms = (time.perf_counter() - t0) * 1e3
                             left -= 1
-                        L.check(lib.mf_cmdlist_replay(handle, left, cur), "mf_cmdlist_replay")
+                        if progress_cb is None:
+                            L.check(lib.mf_cmdlist_replay(handle, left, cur), "mf_cmdlist_replay")
+                        else:   # the same launches in slices of ~5 % of the loop, the callback between them
+                            chunk, done = max(1, len(rev) // 20), len(rev) - left
+                            progress_cb(done, len(rev))
+                            while left > 0:
+                                k = min(chunk, left)
+                                L.check(lib.mf_cmdlist_replay(handle, k, cur), "mf_cmdlist_replay")
+                                left, done = left - k, done + k
+                                progress_cb(done, len(rev))
                 finally:
                     lib.mf_cmdlist_free(handle)    # (the kernarg bytes were copied at every launch)
                 del keep
@@ -458,8 +479,11 @@ class DiffusionPipeline(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):
                     keep = body()
-                for _ in range(done, len(rev)):
+                chunk = max(1, len(rev) // 20)
+                for k in range(done, len(rev)):
                     graph.replay()
+                    if progress_cb is not None and ((k + 1) % chunk == 0 or k + 1 == len(rev)):
+                        progress_cb(k + 1, len(rev))
                 del keep
         torch.cuda.current_stream(dev).wait_stream(side)
         noise.draw_index = base + stride * len(rev)

@@ -104,11 +104,15 @@ class VAE(nn.Module):
         K.SyncWords.reset(x_in.device)
         src = noise if noise is not None else default_noise()
 
+        drawn = []   # the quantizer noise is drawn ONCE: a re-run of the pass (with_fused_fallback) must see the same draw -- a host source cannot be rewound
+
         def run():
             moments = self._encode_moments(x_in)
             n, c2, hh, ww = moments.shape
-            src.begin(n, x_in.device)
-            z_q, _ = self.quantizer(moments, src.draw((n, c2 // 2, hh, ww)))
+            if not drawn:
+                src.begin(n, x_in.device)
+                drawn.append(src.draw((n, c2 // 2, hh, ww)))
+            z_q, _ = self.quantizer(moments, drawn[0])
             emb_loss = K.diag_gaussian_kl(moments)
             out_hor = []
             h = self.inc_dec(z_q.contiguous(), None, in_layout=L.LAYOUT_NCHW)

@@ -45,7 +45,7 @@ def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
     if gcc is None:
         pytest.skip("no gcc")
     structs = {"MfConvDesc": L.MfConvDesc, "MfSchedStep": L.MfSchedStep, "MfSchedArgs": L.MfSchedArgs, "MfGnFuse": L.MfGnFuse, "MfConvF16x2Call": L.MfConvF16x2Call,
-               "MfWinoTail": L.MfWinoTail}
+               "MfWinoTail": L.MfWinoTail, "MfProfRow": L.MfProfRow}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "medfusion_hip.h"', 'int main(void) {']
     for name, cls in structs.items():
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')

@@ -259,6 +259,20 @@ def test_eta_raises_like_reference(dev):
         pipe.sample(1, (8, 8, 8), steps=2, eta=0.0)
 
 
+def test_progress_callback_in_every_loop_form(dev):
+    """denoise(progress_cb=...): the hook where the reference drives st.progress / tqdm (diffusion_pipeline.py:289-291) -- monotone, ends at
+    (total, total), same images with and without it, in the Python loop, the command-list replay and the graph replay"""
+    pipe = build_product_pipe(R.tiny_unet_kwargs(3, "none"), R.tiny_vae_kwargs(), "pipe_tiny", dev)
+    for loop in ("eager", "cmdlist", "graph"):
+        seen = []
+        a = pipe.sample(2, (8, 8, 8), steps=25, noise=M.PhiloxDeviceNoise(5), loop=loop, progress_cb=lambda done, total: seen.append((done, total)))
+        b = pipe.sample(2, (8, 8, 8), steps=25, noise=M.PhiloxDeviceNoise(5), loop=loop)
+        assert torch.equal(a, b), loop
+        assert seen and seen[-1] == (25, 25) and all(t == 25 for _, t in seen), (loop, seen)
+        assert [d for d, _ in seen] == sorted(set(d for d, _ in seen)), (loop, seen)
+        assert len(seen) == 25 if loop == "eager" else len(seen) >= 20, (loop, len(seen))
+
+
 @pytest.fixture(scope="module")
 def published(dev):
     """Published architecture (194 M-parameter UNet + VAE), synthetic weights; oracle on CPU, product on GPU."""

@@ -213,14 +213,22 @@ def test_grouped_conv_res_finds_a_guest_tile_for_every_block_of_cfg2():
     import torch
     shapes = [(16, 16, 16, 256, 0, 512), (16, 8, 8, 512, 0, 1024), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512), (16, 16, 16, 512, 512, 512),
               (16, 16, 16, 512, 256, 256), (16, 32, 32, 256, 256, 256)]
-    for n, h, w, c1, c2, co in shapes:
-        blk = BLK.BasicResBlock(2, c1 + c2, co, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {}))
-        x1 = torch.empty((n, h, w, c1), device="meta")
-        x = x1 if not c2 else (x1, torch.empty((n, h, w, c2), device="meta"))
-        g = blk._grouped(x)
-        assert g is not None, (n, h, w, c1, c2, co)
-        ta, tb = K.conv_plan(g[0])[0], K.conv_plan(g[3])[0]
-        assert (ta in (53, 54) and tb == 53) or (ta in (34, 62) and tb in (36, 37)), (ta, tb)
+    old = BLK.WINOGRAD
+    try:
+        for n, h, w, c1, c2, co in shapes:
+            blk = BLK.BasicResBlock(2, c1 + c2, co, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {}))
+            x1 = torch.empty((n, h, w, c1), device="meta")
+            x = x1 if not c2 else (x1, torch.empty((n, h, w, c2), device="meta"))
+            BLK.WINOGRAD = 0          # the direct form: every pair shares a launch
+            g = blk._grouped(x)
+            assert g is not None, (n, h, w, c1, c2, co)
+            ta, tb = K.conv_plan(g[0])[0], K.conv_plan(g[3])[0]
+            assert (ta in (53, 54) and tb == 53) or (ta in (34, 62) and tb in (36, 37)), (ta, tb)
+            BLK.WINOGRAD = 1          # as shipped: a 3x3 on its Winograd form (csrc/wino_plan_table.inc) runs its own two launches
+            d3 = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 0, precision=5)
+            assert (blk._grouped(x) is None) == K.wino_preferred(d3), (n, h, w, c1, c2, co)
+    finally:
+        BLK.WINOGRAD = old
 
 
 def test_grouped_launch_refuses_shared_scratch_before_launching():
