@@ -611,6 +611,10 @@ class BasicDown(nn.Module):
         super().__init__()
         self.learnable = bool(learnable_interpolation)
         self.use_res = bool(use_res) and self.learnable        # (the reference creates `down_skip` inside the learnable branch only)
+        # the output's fp16-pair form under a bound DERIVED from the operands -- unless its consumer adds it as a RESIDUAL (the VAE's DownBlock /
+        # UpBlock: an identity-residual ResBlock follows): there the derived bound, ~2^12-2^20 above the data, would travel on through every
+        # apply pass of the level (bound = bconst + bound(residual)); that tensor is measured instead (round 5, the bound-slack audit)
+        self.derive_out = True
         if self.learnable:
             self.down_op = Conv(in_channels, out_channels, kernel_size, stride, monai_padding(kernel_size, stride))
         else:
@@ -619,7 +623,7 @@ class BasicDown(nn.Module):
     def forward(self, x, emb=None):
         if self.learnable:
             if not self.use_res:
-                return self.down_op(x, measure_out=f16x2_mode(), derive_out=True)
+                return self.down_op(x, measure_out=f16x2_mode(), derive_out=self.derive_out)
             if isinstance(x, (tuple, list)):
                 raise RuntimeError("BasicDown(use_res=True) takes one tensor")
             return K.pixel_unshuffle2_add(x, self.down_op(x))   # (the sum is measured by its first fp16-pair consumer)
@@ -639,13 +643,14 @@ class BasicUp(nn.Module):
             raise NotImplementedError("BasicUp: only x2 upsampling (kernel_size=stride=2) is supported")
         self.learnable = bool(learnable_interpolation)
         self.use_res = bool(use_res) and self.learnable
+        self.derive_out = True     # (see BasicDown)
         if self.learnable:
             self.up_op = Conv(in_channels, out_channels, 3, 1, 1, upsample=True)
 
     def forward(self, x, emb=None):
         if self.learnable:
             if not self.use_res:
-                return self.up_op(x, measure_out=f16x2_mode(), derive_out=True)
+                return self.up_op(x, measure_out=f16x2_mode(), derive_out=self.derive_out)
             if isinstance(x, (tuple, list)):
                 raise RuntimeError("BasicUp(use_res=True) takes one tensor")
             return K.pixel_shuffle2_add(x, self.up_op(x))
@@ -786,6 +791,8 @@ class DownBlock(nn.Module):
         self.attention = Attention(spatial_dims, down_out, down_out, 8, down_out // 8, norm_name, dropout, emb_channels, 1, use_attention)
         Blk = UnetResBlock if use_res_block else UnetBasicBlock
         self.conv_block = Blk(spatial_dims, down_out, out_channels, kernel_size, 1, norm_name, act_name, dropout, emb_channels)
+        if enable_down and use_res_block and down_out == out_channels:
+            self.down_op.derive_out = False     # its output is the identity residual of conv_block's first ResBlock: measured, not derived
 
     def forward(self, x, emb=None):
         x = self.down_op(x)
@@ -806,6 +813,8 @@ class UpBlock(nn.Module):
         self.attention = Attention(spatial_dims, skip_out, skip_out, 8, skip_out // 8, norm_name, dropout, emb_channels, 1, use_attention)
         Blk = UnetResBlock if use_res_block else UnetBasicBlock
         self.conv_block = Blk(spatial_dims, skip_out, out_channels, kernel_size, 1, norm_name, act_name, dropout, emb_channels)
+        if enable_up and use_res_block and skip_out == out_channels:
+            self.up_op.derive_out = False       # (see DownBlock)
 
     def forward(self, x_enc, x_skip=None, emb=None):
         x = self.up_op(x_enc)

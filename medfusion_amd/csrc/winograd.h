@@ -229,6 +229,26 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
   const int H = p.H, W = p.W, HW = H * W, TW = W >> 1, T = (H >> 1) * TW;
   const long plane = (long)p.N * T * C;
   const int c4 = tid % cq;   // (host: 256 % cq == 0 -- a thread keeps its 4 channels through every loop)
+  // the residual rows of this thread's first RJ elements of phase 2 are requested NOW: they depend on nothing, and their round trip hides behind
+  // phase 1 instead of standing between the statistics and the stores (the tail is a chain of dependent memory round trips: every one removed
+  // is ~1.5 us of a 14 us launch at the 8 x 8 level)
+  constexpr int RJ = 4;
+  uint2 rph[RJ], rpl[RJ];
+  float4 rpf[RJ];
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    rph[j] = make_uint2(0u, 0u); rpl[j] = make_uint2(0u, 0u); rpf[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int it = tid + 256 * j;
+    if (it < HW * cq) {
+      const long eo = ((long)n * HW + it / cq) * C + c0 + c4 * 4;
+      if (p.res_pairs) {
+        const uint2* gp = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(p.res_pairs) + (eo >> 3) * 32 + ((eo >> 2) & 1) * 8);
+        rph[j] = gp[0]; rpl[j] = gp[2];
+      } else if (p.res_f32) {
+        rpf[j] = *reinterpret_cast<const float4*>(p.res_f32 + eo);
+      }
+    }
+  }
   // ---- 1. y = A^T M A + bias into LDS, statistics on the way
   const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   double s = 0, q = 0;
@@ -311,31 +331,44 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
   }
   const float4 em = p.emb ? *reinterpret_cast<const float4*>(p.emb + (long)n * p.emb_stride + c0 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const bool keep = p.out_wino != nullptr;
-  for (int it = tid; it < HW * cq; it += 256) {
-    const int pix = it / cq;
-    float* yp = ys + pix * cpg + c4 * 4;
-    const float4 v = *reinterpret_cast<const float4*>(yp);
-    float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float t = (e[k] - mean) * rstd;
-      if (p.gamma) t = t * ga[k] + be[k];
-      if (p.act == 1) t = swish_apply(t);
-      e[k] = t;
-    }
-    const long eo = ((long)n * HW + pix) * C + c0 + c4 * 4;
-    if (p.res_pairs) {
-      const float4 r = wino_load_pairs4(p.res_pairs, eo);
-      e[0] += r.x * rsc; e[1] += r.y * rsc; e[2] += r.z * rsc; e[3] += r.w * rsc;
-    } else if (p.res_f32) {
-      const float4 r = *reinterpret_cast<const float4*>(p.res_f32 + eo);
-      e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w;
-    }
-    if (p.emb) { e[0] += em.x; e[1] += em.y; e[2] += em.z; e[3] += em.w; }
-    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + eo) = make_float4(e[0], e[1], e[2], e[3]);
-    if (p.out_pairs) store_split4<false>(p.out_pairs, eo, e[0], e[1], e[2], e[3], osc);   // (the bound is derived: no clamp, split_f16.h)
-    if (keep) *reinterpret_cast<float4*>(yp) = make_float4(wino_pair_round(e[0] * osc), wino_pair_round(e[1] * osc), wino_pair_round(e[2] * osc), wino_pair_round(e[3] * osc));
+  auto pairs_to_f4 = [](uint2 h, uint2 l) {
+    const sf_f16x2 h0 = __builtin_bit_cast(sf_f16x2, h.x), h1 = __builtin_bit_cast(sf_f16x2, h.y), l0 = __builtin_bit_cast(sf_f16x2, l.x),
+                   l1 = __builtin_bit_cast(sf_f16x2, l.y);
+    return make_float4((float)h0[0] + (float)l0[0] * kLoInv, (float)h0[1] + (float)l0[1] * kLoInv, (float)h1[0] + (float)l1[0] * kLoInv,
+                       (float)h1[1] + (float)l1[1] * kLoInv);
+  };
+#define WINO_TAIL_ELEMENT(IT, RES_EXPR_PAIRS, RES_EXPR_F32)                                                            \
+  {                                                                                                                   \
+    const int pix = (IT) / cq;                                                                                        \
+    float* yp = ys + pix * cpg + c4 * 4;                                                                              \
+    const float4 v = *reinterpret_cast<const float4*>(yp);                                                            \
+    float e[4] = {v.x, v.y, v.z, v.w};                                                                                \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                   \
+      float t = (e[k] - mean) * rstd;                                                                                 \
+      if (p.gamma) t = t * ga[k] + be[k];                                                                             \
+      if (p.act == 1) t = swish_apply(t);                                                                             \
+      e[k] = t;                                                                                                       \
+    }                                                                                                                 \
+    const long eo = ((long)n * HW + pix) * C + c0 + c4 * 4;                                                           \
+    if (p.res_pairs) {                                                                                                \
+      const float4 r = RES_EXPR_PAIRS;                                                                                \
+      e[0] += r.x * rsc; e[1] += r.y * rsc; e[2] += r.z * rsc; e[3] += r.w * rsc;                                     \
+    } else if (p.res_f32) {                                                                                           \
+      const float4 r = RES_EXPR_F32;                                                                                  \
+      e[0] += r.x; e[1] += r.y; e[2] += r.z; e[3] += r.w;                                                             \
+    }                                                                                                                 \
+    if (p.emb) { e[0] += em.x; e[1] += em.y; e[2] += em.z; e[3] += em.w; }                                            \
+    if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + eo) = make_float4(e[0], e[1], e[2], e[3]);                  \
+    if (p.out_pairs) store_split4<false>(p.out_pairs, eo, e[0], e[1], e[2], e[3], osc);   /* (the bound is derived: no clamp, split_f16.h) */ \
+    if (keep) *reinterpret_cast<float4*>(yp) = make_float4(wino_pair_round(e[0] * osc), wino_pair_round(e[1] * osc), wino_pair_round(e[2] * osc), wino_pair_round(e[3] * osc)); \
   }
+#pragma unroll
+  for (int j = 0; j < RJ; ++j) {
+    const int it = tid + 256 * j;
+    if (it < HW * cq) WINO_TAIL_ELEMENT(it, pairs_to_f4(rph[j], rpl[j]), rpf[j])
+  }
+  for (int it = tid + 256 * RJ; it < HW * cq; it += 256) WINO_TAIL_ELEMENT(it, wino_load_pairs4(p.res_pairs, eo), *reinterpret_cast<const float4*>(p.res_f32 + eo))
+#undef WINO_TAIL_ELEMENT
   if (!keep) return;
   // ---- 3. the input transform of the next Winograd convolution, from the pair-rounded result in LDS: bit for bit what wino_input_kernel
   // makes of out_pairs

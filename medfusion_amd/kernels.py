@@ -223,6 +223,26 @@ def split_conv_weight(w_packed: torch.Tensor) -> torch.Tensor:
 # fp16-pair convolution can MEASURE the bound of its output (measure_out=True); a consumer that finds neither runs the stand-alone
 # passes (max |t| per sample, then the split) once and caches the result on the tensor.  Every wrapper that writes INTO an existing
 # tensor (`out=`) drops stale mirrors first.
+# Bound-slack audit (diagnostic, MEDFUSION_AUDIT_BOUNDS=1 or kernels.AUDIT = True; tests/test_parity_gpu.py::test_trained_like_weights_and_bound_slack):
+# every producer that attaches an fp16-pair mirror under a DERIVED bound records (site, shape, bound / true max per sample) in AUDIT_LOG.  A derived
+# bound sits above the data (the pair format keeps its 23 bits down to 2^-28 of the bound); the audit shows by how much, across a whole network.
+AUDIT = os.environ.get("MEDFUSION_AUDIT_BOUNDS", "0") == "1"
+AUDIT_LOG = []
+
+
+def _audit(t: torch.Tensor, site: str) -> None:
+    """diagnostic only (torch arithmetic, a host sync): decode the pair mirror of `t`, compare its per-sample max with the bound it was scaled by"""
+    if not AUDIT or getattr(t, "_mf_split", None) is None or getattr(t, "_mf_bound", None) is None or torch.cuda.is_current_stream_capturing():
+        return
+    n = t.shape[0]
+    raw = t._mf_split.view(torch.float16).reshape(n, -1, 2, 8).float()
+    bound = t._mf_bound.double()
+    s = torch.floor(torch.log2(bound.clamp_min(1e-300))) - 14
+    amax = (raw[:, :, 0] + raw[:, :, 1] / 2048.0).abs().amax(dim=(1, 2)).double() * torch.exp2(s)
+    slack = (bound / amax.clamp_min(1e-300)).cpu()
+    AUDIT_LOG.append((site, tuple(t.shape), float(slack.max()), float(slack.min()), bool(torch.isfinite(raw).all())))
+
+
 def _stamp(t: torch.Tensor) -> None:
     """remember the tensor's version counter next to its mirrors: a torch in-place op on `t` bumps `_version`, and stale() sees it (writes
     through this library go by raw pointer and do not: every wrapper that writes INTO an existing tensor calls drop_split itself)"""
@@ -337,6 +357,7 @@ def split_of(x: torch.Tensor) -> torch.Tensor:
             s = split_f16x2(x, bound_of(x))
         x._mf_split = s
         _stamp(x)
+        _audit(x, "split of a measured tensor")
     return s
 
 
@@ -459,6 +480,7 @@ def pack_nchw_pairs(x_nchw: torch.Tensor, cp: int = 32) -> torch.Tensor:
     L.check(L.load().mf_pack_nchw_pairs_f32(x.data_ptr(), outs.data_ptr(), ob.data_ptr(), n, c, h * w, cp, stream()), "mf_pack_nchw_pairs_f32")
     out._mf_split, out._mf_bound, out._mf_pairs_only = outs, ob, True
     _stamp(out)
+    _audit(out, "pack_nchw_pairs (measured)")
     return out
 
 
@@ -490,6 +512,7 @@ def conv2d_f16x2_pairs_out(x1: torch.Tensor, w_split, bias: Optional[torch.Tenso
     L.check(rc, "mf_conv2d_f16x2_pairs_out")
     out._mf_split, out._mf_bound = outs, ob
     _stamp(out)
+    _audit(out, "conv pairs_out (derived: bound(x) L1(w) + max|bias|)")
     return out
 
 
@@ -614,6 +637,7 @@ def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor]
     if want_wino:
         out._mf_wino, out._mf_wino_bound = ov, ovb
     _stamp(out)
+    _audit(out, "Winograd tail (derived: bconst + residual + embedding)")
     if not out_fp32:
         out._mf_pairs_only = True
     return out
@@ -669,6 +693,7 @@ def conv2d_f16x2_gn_apply(x1: torch.Tensor, w_split, bias: Optional[torch.Tensor
     L.check(rc, "mf_conv2d_f16x2_gn_apply")
     out._mf_split, out._mf_bound = outs, ob
     _stamp(out)
+    _audit(out, "conv + GroupNorm tail in one launch (derived)")
     if not out_fp32:
         out._mf_pairs_only = True
     return out
@@ -837,6 +862,7 @@ def gn_apply(x: torch.Tensor, stats, gamma, beta, G: int, act: int = 1, residual
     if split:
         out._mf_split, out._mf_bound = outs, ob
         _stamp(out)
+        _audit(out, "GroupNorm apply (derived: bconst + residual + embedding)" if (stats is not None or part is not None) else "apply without norm (bound(x) + residual + embedding)")
         if want_pairs_only:
             out._mf_pairs_only = True
     return out

@@ -259,6 +259,63 @@ def test_eta_raises_like_reference(dev):
         pipe.sample(1, (8, 8, 8), steps=2, eta=0.0)
 
 
+def _trained_like(model, tag):
+    """seeded weights, then every GroupNorm scale log-uniform in [0.01, 30] and every shift uniform in [-5, 5] -- the ranges a trained checkpoint can
+    hold and the synthetic init (gamma ~ 1, beta ~ 0) never visits; zero-init second convolutions are already non-zero under synth_state_dict"""
+    S.synth_state_dict(model, tag)
+    with torch.no_grad():
+        for key, p in model.named_parameters():
+            if key.endswith("norm.weight") or key.endswith("norm_x.weight"):
+                u = S.synth_input("tl_gamma:" + key, tuple(p.shape)).clamp(-1.7320508, 1.7320508) / 1.7320508     # uniform in [-1, 1]
+                p.copy_((torch.exp((u + 1) * 0.5 * np.log(30 / 0.01)) * 0.01).to(p.device))
+            elif key.endswith("norm.bias") or key.endswith("norm_x.bias"):
+                u = S.synth_input("tl_beta:" + key, tuple(p.shape)).clamp(-1.7320508, 1.7320508) / 1.7320508
+                p.copy_((5.0 * u).to(p.device))
+    return model
+
+
+def test_trained_like_weights_and_bound_slack(dev, conv_precision):
+    """GroupNorm scales up to 30 and shifts up to +-5 (what a trained checkpoint may hold) -- one evaluation of the published
+    UNet (B = 4: the 8 x 8 and 16 x 16 levels take the Winograd form where the library can) and one VAE decode against the oracle, on every
+    arithmetic; on the fp16-pair arithmetic every derived operand bound of the two passes is audited against the data it scales
+    (kernels.AUDIT): bound / true max < 2^20 at every site (the pair format keeps 23 bits down to 2^-28 of the bound)."""
+    from medfusion_amd import blocks as BLK
+    ora_u = _trained_like(R.UNet(**R.published_unet_kwargs(2)).eval(), "trained_like.unet.")
+    ora_v = _trained_like(R.VAE(**R.published_vae_kwargs(8)).eval(), "trained_like.vae.")
+    unet = _trained_like(M.UNet(**to_product_kwargs(R.published_unet_kwargs(2))), "trained_like.unet.").to(dev).eval()
+    vae = _trained_like(M.VAE(**R.published_vae_kwargs(8)), "trained_like.vae.").to(dev).eval()
+    x = S.synth_input("tl_x", (4, 8, 32, 32))
+    t = torch.tensor([999, 500, 17, 0])
+    c = torch.tensor([0, 1, 1, 0])
+    z = S.synth_input("tl_z", (1, 8, 32, 32))
+    with torch.no_grad():
+        want_u = ora_u(x, t, c)[0]
+        want_v = ora_v.decode(z)
+    K.AUDIT_LOG.clear()
+    K.AUDIT = conv_precision == 5
+    try:
+        got_u = unet(x.to(dev), t.to(dev), c.to(dev))[0]
+        got_v = vae.decode(z.to(dev))
+    finally:
+        K.AUDIT = False
+    e_u, e_v = relerr_rows(got_u, want_u), relerr(got_v, want_v)
+    print(f"[measured] trained-like weights (gamma in [0.01, 30], beta in [-5, 5]), arithmetic {conv_precision}, WINOGRAD {BLK.WINOGRAD}: "
+          f"UNet per-sample relerr {e_u:.2e}, VAE decode {e_v:.2e}")
+    assert e_u < TOL and e_v < TOL, (e_u, e_v)
+    if conv_precision == 5:
+        assert K.AUDIT_LOG, "the audit saw no fp16-pair producer"
+        worst = {}
+        for site, shape, smax, smin, finite in K.AUDIT_LOG:
+            assert finite, (site, shape)
+            assert smin >= 1.0 - 1e-6, (site, shape, smin)          # a bound below the data would saturate the pairs
+            w = worst.get(site)
+            if w is None or smax > w[0]:
+                worst[site] = (smax, shape)
+        for site, (smax, shape) in sorted(worst.items(), key=lambda kv: -kv[1][0]):
+            print(f"[measured] bound slack, worst over {sum(1 for e in K.AUDIT_LOG if e[0] == site)} tensors: 2^{np.log2(smax):.1f} at {shape} -- {site}")
+        assert max(v[0] for v in worst.values()) < 2.0 ** 20, worst
+
+
 def test_progress_callback_in_every_loop_form(dev):
     """denoise(progress_cb=...): the hook where the reference drives st.progress / tqdm (diffusion_pipeline.py:289-291) -- monotone, ends at
     (total, total), same images with and without it, in the Python loop, the command-list replay and the graph replay"""
