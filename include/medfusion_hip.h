@@ -257,9 +257,14 @@ typedef struct MfWinoTail {
   float bconst, eps;                                         /* bconst >= max |act(gn(y) gamma + beta)| (host constant), GroupNorm eps */
 } MfWinoTail;
 int mf_wino_tail_ok(const MfConvDesc* d, int G);
+/* `guest` (optional): a second, independent fp16-pair convolution -- conv_res of the same ResBlock (conv_blocks.py:238), an ordinary
+ * MfConvF16x2Call as for mf_conv2d_f16x2_group -- whose workgroups share the component GEMM's launch (the GEMM's first, the guest's on the CUs
+ * they leave); bit-identical to its own mf_conv2d_f16x2 call; its output may be the tail's residual (the tail launches behind both).  Ask
+ * mf_wino_group_ok(d, guest->d) first; workspaces and sync arrays of the two must not overlap. */
+int mf_wino_group_ok(const MfConvDesc* d, const MfConvDesc* guest);
 int mf_conv2d_wino_gn_apply_f16x2(const void* v1s, const void* v2s, const void* us, const float* bias, const float* v1_bound, const float* v2_bound,
                                   float u_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, int G, const MfWinoTail* t,
-                                  const MfConvDesc* d, void* stream);
+                                  const MfConvF16x2Call* guest, const MfConvDesc* d, void* stream);
 
 /* Convolution with the statistics of the FOLLOWING GroupNorm (G groups over Cout) fused in: per-tile sums from the
  * epilogue, or from the split-K reducer when the plan splits K.  gn_partial: [N][parts][G][2] doubles {sum, sumsq},

@@ -141,6 +141,7 @@ WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
 
 
 WINO_TAIL = os.environ.get("MEDFUSION_WINOGRAD_TAIL", "1") != "0"   # the GroupNorm / Swish / residual / embedding tail in the launch behind the GEMM (A/B switch; 0: three launches)
+WINO_GROUP = os.environ.get("MEDFUSION_WINOGRAD_GROUP", "1") != "0"  # conv_res in the grid of its ResBlock's component GEMM (A/B switch; 0: its own launch)
 WINO_SHAPES = {}   # tuning hook (scripts/wino_sweep.py / wino_ab.py): (N, H, W, Cin, Cout) -> (tile, split-K) of the component GEMM (0: planner); empty in the product
 if os.environ.get("MEDFUSION_WINOGRAD_TABLE"):   # a JSON list of [N, H, W, Cin, Cout, tile, split-K] (what the sweep writes), for A/B runs without a rebuild
     import json as _json
@@ -233,7 +234,25 @@ class Conv(nn.Module):
             return y, K.GnPartials(partial, parts, gn_eps)
         return y, K.gn_finalize(partial, parts, ho * wo, self.out_ch, gn_groups, gn_eps)   # (more groups than a workgroup has threads)
 
-    def forward_wino_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst):
+    def wino_tail_desc(self, x: Act, G: int):
+        """(descriptor, pinned sizes) of this convolution on the Winograd form with its GroupNorm tail for the input x, or None; cached per shape"""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        key = ("wino_tail", n, h, w, c1, c2, G, WINOGRAD, WINO_TAIL)
+        ent = self._descs.get(key)
+        if ent is None:
+            ent = False
+            if WINO_TAIL and CONV_PRECISION == 5 and self.k == 3 and self.stride == 1 and not self.upsample and c1 + c2 == self.in_ch:
+                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 0, precision=5)
+                if wino_wanted(d) and K.wino_tail_ok(d, G):
+                    wt, wsk = WINO_SHAPES.get((n, h, w, c1 + c2, self.out_ch), (0, 0))
+                    d.tile_hint, d.splitk_hint = wt, wsk
+                    ent = (d, K.pin_wino_plan(d))
+            self._descs[key] = ent
+        return (key, ent) if ent is not False else (key, None)
+
+    def forward_wino_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst, guest=None):
         """conv -> GroupNorm -> Swish -> + residual -> + emb on the Winograd form, the tail in ONE launch behind the component GEMM
         (mf_conv2d_wino_gn_apply_f16x2), or None when this convolution is not on that path for this shape.  The output carries its transform-domain
         mirror as well once a Winograd convolution has asked for it (K.wino_input marks the site): the next call writes it in the tail."""
@@ -243,23 +262,13 @@ class Conv(nn.Module):
         if c1 + c2 != self.in_ch:
             raise RuntimeError(f"conv expects {self.in_ch} input channels, got {c1}+{c2}")
         G = norm.num_groups
-        key = ("wino_tail", n, h, w, c1, c2, G, WINOGRAD, WINO_TAIL)
-        ent = self._descs.get(key)
+        key, ent = self.wino_tail_desc(x, G)
         if ent is None:
-            ent = False
-            if WINO_TAIL and CONV_PRECISION == 5 and self.k == 3 and self.stride == 1 and not self.upsample:
-                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, self.k, self.stride, self.pad, 0, precision=5)
-                if wino_wanted(d) and K.wino_tail_ok(d, G):
-                    wt, wsk = WINO_SHAPES.get((n, h, w, c1 + c2, self.out_ch), (0, 0))
-                    d.tile_hint, d.splitk_hint = wt, wsk
-                    ent = (d, K.pin_wino_plan(d))
-            self._descs[key] = ent
-        if ent is False:
             return None
         d, pinned = ent
         want = self._wino_sites.get(key, False)
         y = K.conv2d_wino_gn_apply(x1, self._packed.get_wino(self.weight), self.bias, d, norm.weight, norm.bias, G, norm.eps, act=act, residual=residual,
-                                   emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, want_wino=want, pinned=pinned)
+                                   emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, want_wino=want, pinned=pinned, guest=guest)
         if not want:
             y._mf_wino_site = (self._wino_sites, key)
         return y
@@ -405,7 +414,8 @@ class BasicBlock(nn.Module):
             self.norm = _norm(norm_name, out_channels)
         self.has_act = act_name is not None
 
-    def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out_fp32=True):
+    def forward(self, x: Act, residual=None, emb=None, emb_stride=0, in_layout=L.LAYOUT_NHWC, out_layout=L.LAYOUT_NHWC, out_fp32=True, wino_guest=None):
+        """wino_guest: conv_res of the enclosing ResBlock for the launch of this block's Winograd component GEMM (BasicResBlock._wino_guest)"""
         has_norm = hasattr(self, "norm")
         if has_norm:
             if out_layout != L.LAYOUT_NHWC:
@@ -414,9 +424,11 @@ class BasicBlock(nn.Module):
                 nm = self.norm
                 x1 = _split(x)[0]
                 y = self.conv.forward_wino_gn_apply(x, nm, int(self.has_act), residual, emb, emb_stride, out_fp32,
-                                                    nm.bound_const(x1.shape[1] * x1.shape[2] * (self.conv.out_ch // nm.num_groups)))
+                                                    nm.bound_const(x1.shape[1] * x1.shape[2] * (self.conv.out_ch // nm.num_groups)), guest=wino_guest)
                 if y is not None:
                     return y
+            if wino_guest is not None:
+                raise RuntimeError("BasicBlock: a guest convolution was planned for a Winograd launch that did not happen")
             if f16x2_mode() and in_layout == L.LAYOUT_NHWC and not K.Rendezvous.disabled:
                 # one launch for conv + GroupNorm + Swish + residual + embedding where the plan allows it (conv_f16x2.h: FuseP)
                 nm = self.norm
@@ -483,8 +495,46 @@ class BasicResBlock(nn.Module):
                     dict(w_split=bb.conv._packed.get_f16x2(bb.conv.weight), bias=bb.conv.bias, d=g[0], gn_groups=nm.num_groups, gn_parts=g[1], pinned=g[2]),
                     dict(w_split=self.conv_res._packed.get_f16x2(self.conv_res.weight), bias=self.conv_res.bias, d=g[3], pinned=g[4]))
                 return bb.finish((y, K.GnPartials(partial, g[1], nm.eps)), res, emb, emb_stride, out_fp32)
+        if WINO_GROUP and GROUPED_CONV_RES and CONV_PRECISION == 5 and WINOGRAD and WINO_TAIL and in_layout == L.LAYOUT_NHWC and hasattr(self.basic_block, "norm"):
+            g = self._wino_guest(x)
+            if g is not None:
+                # the 3x3 runs as Winograd component GEMMs: conv_res joins THAT launch (mf_conv2d_wino_gn_apply_f16x2(..., guest)); the tail behind
+                # it adds conv_res's output as the residual -- bit-identical to the separate conv_res launch
+                cr = self.conv_res
+                return self.basic_block(x, residual=None, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32,
+                                        wino_guest=dict(w_split=cr._packed.get_f16x2(cr.weight), bias=cr.bias, d=g[0], pinned=g[1]))
         res = self.conv_res(x, in_layout=in_layout, measure_out=f16x2_mode())
         return self.basic_block(x, residual=res, emb=emb, emb_stride=emb_stride, in_layout=in_layout, out_fp32=out_fp32)
+
+    def _wino_guest(self, x):
+        """(descriptor, pinned) of conv_res as the guest of the 3x3's Winograd component GEMM for this input shape, or None; cached per shape.
+        The guest keeps the split-K of the plan it has alone (the summation order: same bits as its own launch), on an 8-wave tile."""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        key = ("wino", n, h, w, c1, c2, WINOGRAD, WINO_TAIL)
+        if key in self._group:
+            return self._group[key]
+        ent = None
+        c3, cr, nm = self.basic_block.conv, self.conv_res, self.basic_block.norm
+        _, tail = c3.wino_tail_desc(x, nm.num_groups) if (c1 + c2 == c3.in_ch) else (None, None)
+        if tail is not None and cr.k == 1 and cr.stride == 1:
+            nat = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, precision=5)
+            sk0 = K.conv_plan(nat)[1] if K.conv_f16x2_ok(nat) else 0
+            m = n * h * w
+            t36, t37 = -(-m // 128) * (cr.out_ch // 64), -(-m // 64) * max(cr.out_ch // 256, 1)
+            order = (36, 37) if abs(t36 - 256) <= abs(t37 - 256) or cr.out_ch % 256 else (37, 36)
+            for tile in order:
+                if (tile == 37 and cr.out_ch % 256) or sk0 <= 0:
+                    continue
+                db = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, tile_hint=tile, splitk_hint=sk0, precision=5)
+                if K.conv_f16x2_ok(db) and K.wino_group_ok(tail[0], db):
+                    pb = K.pin_conv_plan(db)
+                    if pb[1] > 0:      # (its output is measured: the tail reads the slot maxima)
+                        ent = (db, pb)
+                        break
+        self._group[key] = ent
+        return ent
 
     def _grouped(self, x):
         """(descriptor, GroupNorm parts, pinned) of the 3x3 + (descriptor, pinned) of conv_res when the two can share a launch for this input

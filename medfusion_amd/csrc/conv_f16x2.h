@@ -90,6 +90,7 @@ struct ConvP2 {
   long slab;
   unsigned bytes1, bytes2, bytesw;
   int subpix, hw_src;
+  int out_nt;            // 1: non-temporal output stores (the component GEMM's output is 4x an activation, read once by the tail)
   int wphase_rows;       // > 0: rows [k wphase_rows, (k + 1) wphase_rows) of the GEMM use weight slab k (the component GEMMs of the Winograd form, winograd.h)
   double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1, or tree)
   int gn_groups, gn_parts, gn_cpg;

@@ -23,6 +23,8 @@ struct Tile2 { int id, BM, BN, WM, WN, NST, HG; };
 const Tile2 kTiles2[] = {
     {31, 128, 256, 2, 4, 3, 0}, {32, 256, 128, 4, 2, 3, 0}, {33, 128, 128, 2, 4, 3, 0}, {34, 128, 128, 4, 2, 3, 0}, {35, 256, 64, 4, 2, 3, 0},
     {36, 128, 64, 4, 2, 3, 0}, {37, 64, 256, 1, 8, 3, 0},
+    // (a four-stage 128 x 128 tile -- one more chunk of look-ahead for the cold weight streams of the Winograd component GEMMs -- measured
+    // 46.2 vs 45.6 us on the 8 x 8 GEMM + tail: not kept; profiles/r05_small_ab.txt)
     // 4-wave workgroups, two per CU (independent barrier cadences on the two waves of a SIMD)
     {51, 128, 128, 2, 2, 2, 0}, {52, 128, 128, 2, 2, 3, 0}, {53, 64, 128, 2, 2, 3, 0}, {54, 128, 64, 2, 2, 3, 0},
     // halo tiles: activations staged once per chunk
@@ -253,6 +255,8 @@ int launch_group(const mfc2::ConvP2& pa, const mfc2::ConvP2& pb, hipStream_t s, 
   return check_launch("conv_f16x2_group");
 }
 int dispatch_group(int ida, int idb, const mfc2::ConvP2& pa, const mfc2::ConvP2& pb, hipStream_t s, int mode) {
+  using T31 = mfc2::PlainTile<128, 256, 2, 4, 3>;
+  using T33 = mfc2::PlainTile<128, 128, 2, 4, 3>;
   using T34 = mfc2::PlainTile<128, 128, 4, 2, 3>;
   using T36 = mfc2::PlainTile<128, 64, 4, 2, 3>;
   using T37 = mfc2::PlainTile<64, 256, 1, 8, 3>;
@@ -266,6 +270,11 @@ int dispatch_group(int ida, int idb, const mfc2::ConvP2& pa, const mfc2::ConvP2&
     case 3437: return launch_group<T34, T37>(pa, pb, s, mode);
     case 6236: return launch_group<T62, T36>(pa, pb, s, mode);
     case 6237: return launch_group<T62, T37>(pa, pb, s, mode);
+    // the component GEMM of a Winograd convolution as the host (round 5: conv_res in ITS grid -- mf_conv2d_wino_gn_apply_f16x2(..., guest))
+    case 3336: return launch_group<T33, T36>(pa, pb, s, mode);
+    case 3337: return launch_group<T33, T37>(pa, pb, s, mode);
+    case 3136: return launch_group<T31, T36>(pa, pb, s, mode);
+    case 3137: return launch_group<T31, T37>(pa, pb, s, mode);
     default: return -1;
   }
 }
@@ -524,6 +533,7 @@ static int conv_f16x2_prepare(const void* x1s, const void* x2s, const void* ws, 
   p.bytes2 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C2);
   p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : wino_gemm ? 16 : 1));
   p.wphase_rows = wino_gemm ? (d->N / 16) * d->Hin * d->Win : 0;
+  p.out_nt = 0;   // (non-temporal stores for the component GEMM's output: 397.54 vs 397.53 ms on the cfg2 step -- nothing; the hook stays for A/B builds)
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
 #if MFC2_HZ & (256 | 512)

@@ -66,7 +66,9 @@ __device__ __forceinline__ void split8_f16(const sf_f32x4 v0, const sf_f32x4 v1,
 // group and both execute the call (thread index == float4 index modulo an even stride, even float4 count): the pair swaps one 8-byte
 // piece through DPP so that each lane stores ONE full 16-byte slot ([hi x 8] by the even lane, [lo' x 8] by the odd one) -- a wave
 // writes 1 KB contiguously with one instruction instead of two half-filled ones.
-template <bool CLAMP = true>
+// NT: the 16-byte store as a non-temporal one (streamed past the L2's dirty set: for outputs that are 4x an activation and read once, by
+// another kernel -- the transform-domain tensors of the Winograd form)
+template <bool CLAMP = true, bool NT = false>
 __device__ __forceinline__ void store_split4(void* ys, long e, float a, float b, float c, float d, float sc) {
   unsigned h0, h1, l0, l1;
   split2_f16<CLAMP>(a * sc, b * sc, h0, l0);
@@ -80,7 +82,8 @@ __device__ __forceinline__ void store_split4(void* ys, long e, float a, float b,
   sf_u32x4* q_ = reinterpret_cast<sf_u32x4*>(ys) + ((e >> 3) * 2 + (odd ? 1 : 0));
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q_), "v"(v) : "memory");
 #else
-  reinterpret_cast<sf_u32x4*>(ys)[(e >> 3) * 2 + (odd ? 1 : 0)] = v;
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<sf_u32x4*>(ys) + ((e >> 3) * 2 + (odd ? 1 : 0)));
+  else reinterpret_cast<sf_u32x4*>(ys)[(e >> 3) * 2 + (odd ? 1 : 0)] = v;
 #endif
 }
 

@@ -211,6 +211,7 @@ struct WinoTailP {
   float* wino_bound;            // [16 N]
   int N, H, W, C, G, act;
   float eps, bconst;
+  int v_nt;                     // 1: the transform-domain output goes out with non-temporal stores (MF_WINO_VSTORE, A/B)
 };
 
 // the value a pair (hi, lo') stands for, still scaled: RN16(a) + RN16((a - RN16(a)) 2048) / 2048 -- what wino_load_pairs4 reads back
@@ -389,8 +390,13 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) wino_bt_d_b(d[k]);
     const long e0 = ((long)n * T + t) * C + c0 + c4 * 4;
+    if (p.v_nt) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) store_split4<true>(p.out_wino, (long)k * plane + e0, d[0][k], d[1][k], d[2][k], d[3][k], f);
+      for (int k = 0; k < 16; ++k) store_split4<true, true>(p.out_wino, (long)k * plane + e0, d[0][k], d[1][k], d[2][k], d[3][k], f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) store_split4<true>(p.out_wino, (long)k * plane + e0, d[0][k], d[1][k], d[2][k], d[3][k], f);
+    }
   }
 }
 

@@ -594,12 +594,20 @@ def wino_tail_ok(d: L.MfConvDesc, G: int) -> bool:
     return bool(L.load().mf_wino_tail_ok(C.byref(d), G))
 
 
+def wino_group_ok(d: L.MfConvDesc, guest: L.MfConvDesc) -> bool:
+    """can the fp16-pair convolution `guest` share the launch of d's component GEMM (mf_wino_group_ok)?"""
+    return bool(L.load().mf_wino_group_ok(C.byref(d), C.byref(guest)))
+
+
 def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor], d: L.MfConvDesc, gamma, beta, G: int, eps: float, act: int = 1,
                          residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
-                         x2: Optional[torch.Tensor] = None, bconst: float = 0.0, out_fp32: bool = True, want_wino: bool = False, pinned=None) -> torch.Tensor:
+                         x2: Optional[torch.Tensor] = None, bconst: float = 0.0, out_fp32: bool = True, want_wino: bool = False, pinned=None,
+                         guest=None) -> torch.Tensor:
     """Winograd conv -> GroupNorm -> Swish -> (+ residual) -> (+ emb) (-> the input transform of the next Winograd convolution) in two launches
     (mf_conv2d_wino_gn_apply_f16x2): the component GEMM and one tail.  Returns the result with its fp16-pair mirror and bound attached (out_fp32 =
-    False: pairs only, like gn_apply) and, with want_wino, its transform-domain mirror as well."""
+    False: pairs only, like gn_apply) and, with want_wino, its transform-domain mirror as well.
+    guest = dict(w_split, bias, d, pinned): conv_res of the same ResBlock (a 1x1 on the same x1 | x2) in the GEMM's grid; its measured output IS the
+    residual of the tail (`residual` must be None then)."""
     uh, umax = u_split
     _gpu(x1, x2, uh, bias, gamma, beta, residual, emb)
     lib = L.load()
@@ -607,6 +615,30 @@ def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor]
     v2, b2 = wino_input(x2) if x2 is not None else (None, None)
     n, h, w, c = d.N, d.Hin, d.Win, d.Cout
     dev = x1.device
+    need, words = pinned if pinned is not None else pin_wino_plan(d)
+    gcall = None
+    if guest is not None:
+        if residual is not None:
+            raise RuntimeError("conv2d_wino_gn_apply: the guest's output is the residual")
+        dg = guest["d"]
+        need_g, slots_g, words_g = guest["pinned"]
+        off_g = (need + 255) & ~255                      # the guest's hand-off region behind the GEMM's workspace, its counters behind the GEMM's
+        ws = Workspace.get(off_g + need_g, dev)
+        sync = SyncWords.get(words + words_g, dev) if (words or words_g) else None
+        x1s, xb1 = split_of(x1), bound_of(x1)
+        x2s, xb2 = (split_of(x2), bound_of(x2)) if x2 is not None else (None, None)
+        hog, wog = conv_out_hw(dg)
+        residual = torch.empty((dg.N, hog, wog, dg.Cout), dtype=torch.float32, device=dev)
+        gslots = torch.empty((dg.N, slots_g), dtype=torch.float32, device=dev) if slots_g else None
+        wg, wgmax = guest["w_split"]
+        gcall = L.MfConvF16x2Call(x1s.data_ptr(), _ptr(x2s), wg.data_ptr(), _ptr(guest["bias"]), residual.data_ptr(), xb1.data_ptr(), _ptr(xb2), wgmax, _ptr(gslots),
+                                  ws.data_ptr() + off_g if need_g else None, need_g, sync.data_ptr() + 4 * words if words_g else None, None, 0, C.pointer(dg))
+        if slots_g:
+            residual._mf_slots = gslots
+            _stamp(residual)
+    else:
+        ws = Workspace.get(need, dev)
+        sync = SyncWords.get(words, dev) if words else None
     res_pairs = rb = rslots = eb = None
     if residual is not None:
         if pairs_only(residual):
@@ -624,14 +656,11 @@ def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor]
     ob = torch.empty((n,), dtype=torch.float32, device=dev)
     ov = torch.empty((16, n, (h // 2) * (w // 2), c), dtype=torch.int32, device=dev) if want_wino else None
     ovb = torch.empty((16 * n,), dtype=torch.float32, device=dev) if want_wino else None
-    need, words = pinned if pinned is not None else pin_wino_plan(d)
-    ws = Workspace.get(need, dev)
-    sync = SyncWords.get(words, dev) if words else None
     t = L.MfWinoTail(_ptr(gamma), _ptr(beta), None if res_pairs is not None else _ptr(residual), _ptr(res_pairs), _ptr(rb), _ptr(rslots), _ptr(emb), _ptr(eb),
                      out.data_ptr() if out_fp32 else None, outs.data_ptr(), ob.data_ptr(), _ptr(ov), _ptr(ovb), int(emb_stride),
                      0 if rslots is None else rslots.shape[1], int(act), float(bconst), float(eps))
     rc = lib.mf_conv2d_wino_gn_apply_f16x2(v1.data_ptr(), _ptr(v2), uh.data_ptr(), _ptr(bias), b1.data_ptr(), _ptr(b2), umax, ws.data_ptr(), need, _ptr(sync), G,
-                                           C.byref(t), C.byref(d), stream())
+                                           C.byref(t), None if gcall is None else C.byref(gcall), C.byref(d), stream())
     L.check(rc, "mf_conv2d_wino_gn_apply_f16x2")
     out._mf_split, out._mf_bound = outs, ob
     if want_wino:

@@ -94,7 +94,9 @@ _SIGS = {
     "mf_wino_plan_query": (_I, [C.POINTER(MfConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mf_conv2d_wino_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_wino_tail_ok": (_I, [C.POINTER(MfConvDesc), _I]),
-    "mf_conv2d_wino_gn_apply_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, _I, C.POINTER(MfWinoTail), C.POINTER(MfConvDesc), c_fp]),
+    "mf_wino_group_ok": (_I, [C.POINTER(MfConvDesc), C.POINTER(MfConvDesc)]),
+    "mf_conv2d_wino_gn_apply_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, _I, C.POINTER(MfWinoTail), C.POINTER(MfConvF16x2Call),
+                                           C.POINTER(MfConvDesc), c_fp]),
     "mf_maxabs_rows_slots": (_I, [_I64]),
     "mf_maxabs_rows_f32": (_I, [c_fp, c_fp, c_fp, _I, _I64, c_fp]),
     "mf_bound_finalize_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),

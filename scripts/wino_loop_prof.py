@@ -10,7 +10,7 @@ from medfusion_amd import blocks as BLK, kernels as K, published as P
 
 dev = torch.device("cuda:0")
 pipe = P.build_published_pipeline(dev, None)
-B, ITS = 16, 30
+B, ITS = int(os.environ.get("WINO_B", "16")), 30
 modes = [int(m) for m in os.environ.get("WINO_MODES", "0,1").split(",")]
 for mode in modes:
     BLK.WINOGRAD = mode

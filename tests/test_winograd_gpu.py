@@ -291,3 +291,36 @@ def test_winograd_sites_learn_to_write_the_transform_domain(dev):
     # GEMM + tail of each of the two convolutions (4) -- block 0's output comes with its transform-domain mirror, x keeps its cached one
     assert counts[1] == counts[2] == 6 and counts[0] > counts[1], counts
     print(f"[measured] launches of a UnetResBlock on the Winograd form: first evaluation {counts[0]}, later {counts[1]}")
+
+
+@pytest.mark.parametrize("shape", [(16, 8, 8, 512, 0, 1024), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512), (16, 16, 16, 512, 512, 512), (16, 16, 16, 512, 256, 256)])
+def test_conv_res_in_the_grid_of_the_component_gemm(dev, shape):
+    """conv_res (1x1) of a channel-changing ResBlock as the GUEST of its 3x3's Winograd component GEMM (mf_conv2d_wino_gn_apply_f16x2(..., guest)):
+    the same bits as conv_res in a launch of its own, one launch fewer"""
+    import ctypes as C
+    from medfusion_amd import blocks as BLK, kernels as K, lib as L
+    n, h, w, c1, c2, co = shape
+    blk = BLK.BasicResBlock(2, c1 + c2, co, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {})).to(dev)
+    S.synth_state_dict(blk, f"winogrp{shape}.")
+    x1 = K.nchw_to_nhwc(_rand(f"wgx{shape}", (n, c1, h, w)).to(dev))
+    x2 = K.nchw_to_nhwc(_rand(f"wgy{shape}", (n, c2, h, w)).to(dev)) if c2 else None
+    x = x1 if x2 is None else (x1, x2)
+    lib = L.load()
+    old = BLK.WINOGRAD, BLK.WINO_GROUP
+    outs, counts = {}, {}
+    try:
+        BLK.WINOGRAD = 2
+        for grp in (False, True):
+            BLK.WINO_GROUP = grp
+            blk(x)                                  # (weights packed, mirrors cached)
+            handle = C.c_void_p()
+            L.check(lib.mf_cmdlist_begin(), "begin")
+            outs[grp] = blk(x).clone()
+            L.check(lib.mf_cmdlist_end(C.byref(handle)), "end")
+            counts[grp] = lib.mf_cmdlist_count(handle)
+            lib.mf_cmdlist_free(handle)
+        assert blk._wino_guest(x) is not None, shape
+    finally:
+        BLK.WINOGRAD, BLK.WINO_GROUP = old
+    assert torch.equal(outs[True], outs[False]), shape
+    assert counts[True] == counts[False] - 1 == 2, counts     # GEMM (+ conv_res in its grid) and the tail
