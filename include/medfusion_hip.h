@@ -131,6 +131,8 @@ int mf_conv2d_f16x2(const void* x1s, const void* x2s, const void* ws, const floa
 int mf_conv2d_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
 /* A run-time override of the planner's choice for the shape of `d` (ABI 220; tile = 0 removes it): consulted before the built-in table when the
  * descriptor carries no hints.  For tuning inside the real pipeline (scripts/plan_tune.py) -- the table is what ships. */
+/* (a caller that caches plan-derived sizes -- workspace bytes, sync words, bound slots, which pairs share a launch -- drops them when it installs an
+ * override: the Python host's per-module caches are cleared by the tuning scripts that use this entry, scripts/plan_tune.py:clear_caches) */
 int mf_conv2d_plan_override(const MfConvDesc* d, int tile, int splitk);
 
 /* TWO independent fp16-pair convolutions in ONE launch (ABI 220; BasicResBlock.forward, conv_blocks.py:194-240: `conv_res(x)` (:238) and the 3x3

@@ -927,6 +927,29 @@ def test_gn_apply_from_partials_with_residual_bound_slots(dev):
     assert torch.equal(a._mf_split, K.split_f16x2(a, a._mf_bound))
 
 
+def test_an_understated_operand_bound_fails_loudly(dev):
+    """the apply pass and the fused tails split WITHOUT the fp16 range clamp (their bound is derived, the clamp can never act).  What an
+    UNDERSTATED bound does -- a caller of the C-ABI handing in a residual bound below the data -- is therefore defined here: the scaled value leaves
+    the fp16 range, its pair becomes (Inf, NaN), and the convolution that consumes the tensor returns non-finite numbers for the samples concerned.
+    Loud, not silently saturated (a clamp would hand a finite, wrong operand to the next layer); samples whose bound holds are untouched."""
+    from medfusion_amd import kernels as K
+    n, h, w, c, g = 2, 8, 8, 64, 8
+    y = K.nchw_to_nhwc(_rand("ub_y", (n, c, h, w)).to(dev))
+    res = K.nchw_to_nhwc(_rand("ub_r", (n, c, h, w), 50.0).to(dev))
+    partial, parts = K.gn_stats_partial(y, g)
+    true_b = res.abs().amax(dim=(1, 2, 3))
+    res._mf_bound = torch.stack([true_b[0], true_b[1] / 64.0])          # sample 1: understated by 2^6
+    K._stamp(res)
+    out = K.gn_apply(y, K.GnPartials(partial, parts, 1e-5), None, None, g, 1, res, split=True, bconst=1e-3)   # (bconst tiny: the residual bound carries the scale)
+    assert bool(torch.isfinite(out).all())                               # the fp32 form is what it is
+    raw = out._mf_split.view(torch.float16).reshape(n, -1).float()
+    assert bool(torch.isfinite(raw[0]).all()) and not bool(torch.isfinite(raw[1]).all())
+    wt = _rand("ub_w", (64, c, 3, 3), 0.05).to(dev)
+    d = K.make_conv_desc(n, h, w, c, 0, 64, 3, 1, 1, 0, precision=5)
+    z = K.conv2d_f16x2(out, K.split_weight_f16x2(K.pack_conv_weight(wt)), None, d)
+    assert bool(torch.isfinite(z[0]).all()) and not bool(torch.isfinite(z[1]).all())
+
+
 def test_gn_apply_pairs_only_output_and_residual_from_pairs(dev):
     """between the two convolutions of a ResBlock the activation exists as fp16 pairs only: the apply pass writes no fp32 (out_fp32=False)
     and the next pass reads its residual from the pairs -- the pairs are bit-identical to those of the ordinary pass, the residual read
