@@ -1232,7 +1232,7 @@ def test_fused_rendezvous_timeout_falls_back_to_the_two_launch_form(dev, tmp_pat
     script.write_text(FAULT.format(root=str(ROOT)))
     outs = {}
     for tag, env_extra in (("fault", {"MEDFUSION_FUSE_FAULT": "1", "MEDFUSION_FUSED_APPLY": "1"}), ("off", {"MEDFUSION_FUSED_APPLY": "0"}), ("on", {"MEDFUSION_FUSED_APPLY": "1"})):
-        env = dict(os.environ, **env_extra)
+        env = dict(os.environ, MEDFUSION_WINOGRAD="0", **env_extra)    # (a feature of the direct form: the Winograd form has its own tail)
         r = subprocess.run([sys.executable, str(script), str(tmp_path / f"{tag}.pt")], env=env, capture_output=True, text=True, timeout=900, cwd=str(ROOT))
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         outs[tag] = (torch.load(tmp_path / f"{tag}.pt"), [ln for ln in r.stdout.splitlines() if ln.startswith("FAULT_MODE")][-1])
@@ -1391,8 +1391,9 @@ def test_grouped_conv_res_inside_the_blocks(dev):
     S.synth_state_dict(blk, "grp.")
     x = K.nchw_to_nhwc(_rand("grpx", (16, 256, 16, 16)).to(dev))
     emb = _rand("grpe", (16, 512)).to(dev)
-    old = BLK.GROUPED_CONV_RES
+    old, old_w = BLK.GROUPED_CONV_RES, BLK.WINOGRAD
     try:
+        BLK.WINOGRAD = 0        # (the direct form's grouped launch; the Winograd form's: tests/test_winograd_gpu.py)
         BLK.GROUPED_CONV_RES = False
         want = blk(x, emb=emb, emb_stride=512)
         BLK.GROUPED_CONV_RES = True
@@ -1405,4 +1406,4 @@ def test_grouped_conv_res_inside_the_blocks(dev):
         BLK.GROUPED_CONV_RES = True
         assert torch.equal(blk(xo, emb=emb[:2], emb_stride=512), want_o)
     finally:
-        BLK.GROUPED_CONV_RES = old
+        BLK.GROUPED_CONV_RES, BLK.WINOGRAD = old, old_w
