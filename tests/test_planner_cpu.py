@@ -343,3 +343,51 @@ def test_pair_planner_properties_over_many_descriptors():
                     assert sq == 1 or lib.mf_conv2d_f16x2_sync_words(C.byref(q)) > 0
                 assert tiles[K.conv_plan(d)[0]][2] == tiles[K.conv_plan(g)[0]][2]      # one workgroup size
     assert n_ok > 200 and n_tree > 20 and n_group >= 1, (n_ok, n_tree, n_group)
+
+
+def _wino_table():
+    import re
+    from pathlib import Path
+    txt = (Path(__file__).resolve().parents[1] / "medfusion_amd" / "csrc" / "wino_plan_table.inc").read_text()
+    return [tuple(int(v) for v in m.groups()) for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+)\},", txt, re.M)]
+
+
+def test_every_winograd_table_entry_is_runnable_with_its_tail():
+    """csrc/wino_plan_table.inc (the shapes the Winograd form measured faster on): every entry is a 3x3 the library can run in that form with the
+    GroupNorm tail of the published models (32 groups), its component GEMM finishes inside its launch, and the sizes the host asks for are
+    consistent (workspace = the GEMM's output in the transform domain + its split-K hand-off; parts = the output transform's workgroups per sample)"""
+    lib = L.load()
+    table = _wino_table()
+    assert len(set(table)) >= 40      # (the B = 16 / latent 64 sweep re-measured two shapes of the latent-32 one: listed twice, harmless)
+    for n, h, w, cin, co in sorted(set(table)):
+        for c1, c2 in ((cin, 0), (cin - co, co)) if cin > co and (cin - co) % 32 == 0 else ((cin, 0),):
+            d = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 0, precision=5)
+            assert K.wino_ok(d) and K.wino_preferred(d) and K.wino_tail_ok(d, 32), (n, h, w, cin, co)
+            t, sk = C.c_int32(), C.c_int32()
+            lib.mf_wino_plan_query(C.byref(d), C.byref(t), C.byref(sk))
+            assert t.value in (31, 32, 33, 34, 35, 36, 37, 51, 52, 53, 54) and sk.value >= 1 and sk.value & (sk.value - 1) == 0
+            m_bytes = 16 * n * (h // 2) * (w // 2) * co * 4
+            ws = lib.mf_wino_workspace_bytes(C.byref(d))
+            assert ws >= m_bytes and (ws == m_bytes) == (sk.value == 1)
+            assert (lib.mf_wino_sync_words(C.byref(d)) > 0) == (sk.value > 1)
+            assert K.wino_gn_parts(d, 32) >= 1
+    # the direct form keeps everything else: the 32 x 32 level of the 256-px models, strided / 1x1 / up-sampling convolutions, the exact arithmetics
+    for bad in (K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5), K.make_conv_desc(16, 8, 8, 1024, 0, 1024, 1, 1, 0, 0, precision=5),
+                K.make_conv_desc(16, 16, 16, 512, 0, 512, 3, 2, 1, 0, precision=5), K.make_conv_desc(16, 8, 8, 1024, 0, 1024, 3, 1, 1, 0, precision=0),
+                K.make_conv_desc(16, 8, 8, 1024, 0, 1024, 3, 1, 1, 0, precision=3)):
+        assert not K.wino_preferred(bad)
+
+
+def test_conv_res_finds_its_place_in_the_component_gemm_launch():
+    """every channel-changing ResBlock of cfg2 whose 3x3 is on the Winograd form takes its conv_res into the component GEMM's launch"""
+    from medfusion_amd import blocks as BLK
+    import torch
+    for n, h, w, c1, c2, co in [(16, 8, 8, 512, 0, 1024), (16, 8, 8, 1024, 1024, 1024), (16, 8, 8, 1024, 512, 512), (16, 16, 16, 512, 512, 512), (16, 16, 16, 512, 256, 256),
+                                (8, 8, 8, 1024, 1024, 1024), (32, 8, 8, 512, 0, 1024)]:
+        blk = BLK.BasicResBlock(2, c1 + c2, co, 3, 1, ("GROUP", {"num_groups": 32, "affine": True}), ("Swish", {}))
+        x1 = torch.empty((n, h, w, c1), device="meta")
+        x = x1 if not c2 else (x1, torch.empty((n, h, w, c2), device="meta"))
+        g = blk._wino_guest(x)
+        assert g is not None, (n, h, w, c1, c2, co)
+        assert K.conv_plan(g[0])[0] in (36, 37) and g[1][1] > 0      # an 8-wave guest tile; its output is measured (bound slots)
+        assert blk._grouped(x) is None                                # (the direct form's grouped launch steps aside)
