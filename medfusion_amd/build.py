@@ -136,6 +136,45 @@ def build_variant(name: str, conv_flags=(), packed_fp32: bool = False, verbose: 
     return lib
 
 
+def asan_runtime() -> Path:
+    """the AddressSanitizer runtime of the ROCm clang (to LD_PRELOAD in front of a python that loads the ASAN twin)"""
+    clang = Path(hipcc()).resolve().parent.parent / "lib" / "llvm" / "bin" / "clang"
+    if not clang.exists():
+        clang = Path("/opt/rocm/lib/llvm/bin/clang")
+    out = subprocess.run([str(clang), "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True, check=True).stdout.strip()
+    return Path(out)
+
+
+def build_asan(verbose: bool = False) -> Path:
+    """The HOST side of the library under AddressSanitizer (sanitizers row): csrc/build/variants/libmedfusion_hip_asan.so -- every
+    unit recompiled with -fsanitize=address for the host pass only (planner, descriptor validation, workspace arithmetic, command lists, the timing
+    registry: the code a wrong struct layout or a bad size would corrupt), device code unchanged.  Use:
+        LD_PRELOAD=$(python -c "from medfusion_amd.build import asan_runtime; print(asan_runtime())") ASAN_OPTIONS=detect_leaks=0 \
+        MEDFUSION_LIB=<the path this returns> python -m pytest tests -m "not gpu"
+    (tests/test_boundary_cpu.py::test_host_side_under_address_sanitizer runs the planner and boundary tests that way)."""
+    vdir = OBJ / "variants"
+    vdir.mkdir(parents=True, exist_ok=True)
+    lib = vdir / "libmedfusion_hip_asan.so"
+    if not _stale(lib, [CSRC / s for s in SOURCES] + _deps() + [Path(__file__)]):
+        return lib
+    san = ["-Xarch_host", "-fsanitize=address", "-Xarch_host", "-fno-omit-frame-pointer", "-g"]
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = vdir / f"{Path(src).stem}_asan.o"
+        objs.append(obj)
+        jobs.append([hipcc(), *CFLAGS, *EXTRA_CFLAGS.get(src, []), *san, "-c", str(CSRC / src), "-o", str(obj)])
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    tmp = lib.with_name(f".{lib.name}.{os.getpid()}.tmp")
+    try:
+        _run([hipcc(), *LFLAGS, "-fsanitize=address", "-shared-libsan", *[str(o) for o in objs], "-o", str(tmp)], verbose)
+        os.replace(tmp, lib)      # (not loaded here: it needs its runtime preloaded)
+    finally:
+        if tmp.exists():
+            tmp.unlink()
+    return lib
+
+
 # gfx950 erratum (scripts/pk_repro_min.hip, profiles/r03_pk_repro.txt): a packed fp32 VALU instruction whose LOW result takes the HIGH half of
 # src1 (op_sel's second bit set: "v_pk_mul_f32 vD, vA, vB op_sel:[0,1]") reads that operand as 0.0 in lanes 48..63 now and then, when the
 # other wave of the SIMD issues matrix instructions while LDS reads return.  hipcc 7.2 forms that operand selection by itself when it packs
@@ -163,6 +202,8 @@ def lint_isa(verbose: bool = False):
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True), "(runtime to preload:", asan_runtime(), ")")
     if "--lint" in sys.argv:
         bad = lint_isa()
         print("ISA lint:", "clean" if not bad else bad)

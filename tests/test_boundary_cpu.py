@@ -223,3 +223,27 @@ int main(void) {
     want = K.conv_plan(K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5))
     assert (ver, rc, ok) == (230, 0, 1) and (tile, sk) == want
     assert out[1].startswith("0|") and "unsupported" in out[1]
+
+
+def test_host_side_under_address_sanitizer():
+    """SURVEY section 5 (sanitizers row): the library's HOST side -- planner, descriptor validation, workspace arithmetic, the Winograd plan and
+    table queries, struct passing through ctypes -- recompiled with -fsanitize=address (medfusion_amd.build.build_asan: host pass only, device
+    code unchanged) and driven by the planner tests and the host-validation tests of this file in a subprocess that preloads the sanitizer's
+    runtime: no report, same results."""
+    import os
+    import subprocess
+    import sys
+    from medfusion_amd import build as B
+    try:
+        rt = B.asan_runtime()
+    except (subprocess.CalledProcessError, OSError, RuntimeError):
+        pytest.skip("no clang AddressSanitizer runtime in this image")
+    if not rt.exists():
+        pytest.skip("no clang AddressSanitizer runtime in this image")
+    lib = B.build_asan()
+    env = dict(os.environ, LD_PRELOAD=str(rt), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", MEDFUSION_LIB=str(lib))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "tests/test_planner_cpu.py",
+                        "tests/test_boundary_cpu.py::test_host_validation_without_gpu", "tests/test_boundary_cpu.py::test_struct_layouts_match_header"],
+                       cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stdout + r.stderr, (r.stdout[-3000:], r.stderr[-3000:])
+    assert " passed" in r.stdout
