@@ -74,6 +74,8 @@ for name, cl in cands.items():
     if key in seen_keys:      # (c0 / c1 of different blocks share a shape: one plan)
         continue
     seen_keys.add(key)
+    if d.KH == 3 and d.stride == 1 and d.upsample == 0 and K.wino_preferred(d):   # (round 5: this shape runs on its Winograd form -- its direct plan is not in the loop)
+        continue
     lib.mf_conv2d_plan_override(C.byref(d), 0, 0)
     cur = K.conv_plan(d)
     res = {}
