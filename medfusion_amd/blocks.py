@@ -578,17 +578,17 @@ class BasicResBlock(nn.Module):
         self._group[key] = ent
         return ent
 
-    def reads_pairs_only(self, n: int, h: int, w: int) -> bool:
-        """can this block take an [n, h, w, Cin] input that exists as fp16 pairs only?  Its convolutions must be on the fp16-pair kernel FOR
-        THAT SHAPE (its residual add reads pairs anyway): asked of the planner itself (mf_conv2d_f16x2_ok on the real descriptor -- tensor
-        size limits, tile fits -- not guessed from channel counts: ADVICE r03), cached per shape"""
+    def reads_pairs_only(self, n: int, h: int, w: int, c2: int = 0) -> bool:
+        """can this block take an [n, h, w, Cin] input (c2 > 0: a fused concat whose second source has c2 channels) that exists as fp16 pairs only?
+        Its convolutions must be on the fp16-pair kernel FOR THAT SHAPE (its residual add reads pairs anyway): asked of the planner itself
+        (mf_conv2d_f16x2_ok on the real descriptor -- tensor size limits, tile fits -- not guessed from channel counts: ADVICE r03), cached per shape"""
         if not (f16x2_mode() and hasattr(self.basic_block, "norm")):
             return False
-        key = (n, h, w, CONV_PRECISION)
+        key = (n, h, w, c2, CONV_PRECISION)
         ok = self._pairs_ok.get(key)
         if ok is None:
             convs = [self.basic_block.conv] + ([] if isinstance(self.conv_res, nn.Identity) else [self.conv_res])
-            ok = all(K.conv_f16x2_ok(K.make_conv_desc(n, h, w, c.in_ch, 0, c.out_ch, c.k, c.stride, c.pad, 0, precision=CONV_PRECISION)) for c in convs)
+            ok = all(c.in_ch > c2 and K.conv_f16x2_ok(K.make_conv_desc(n, h, w, c.in_ch - c2, c2, c.out_ch, c.k, c.stride, c.pad, 0, precision=CONV_PRECISION)) for c in convs)
             self._pairs_ok[key] = ok
         return ok
 
@@ -609,9 +609,10 @@ class _EmbBlock(nn.Module):
             # Swish -> Linear(emb_channels, out_channels); index 1 carries the parameters (key `local_embedder.1.*`)
             self.local_embedder = nn.Sequential(nn.Identity(), nn.Linear(emb_channels, out_channels))
 
-    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, in_layout=L.LAYOUT_NHWC):
+    def forward(self, x: Act, emb: Optional[torch.Tensor] = None, in_layout=L.LAYOUT_NHWC, out_fp32: bool = True):
         """`emb`: the block's *local* embedding [B, Cout] (already through Swish->Linear; the UNet batches
-        all local embedders into one GEMM), possibly a strided view into a wider matrix."""
+        all local embedders into one GEMM), possibly a strided view into a wider matrix.
+        out_fp32=False: the caller promises that the block's OUTPUT is read by fp16-pair convolutions and residual adds only (UNet.features)."""
         n = len(self.block_seq)
         last = n if self.emb_after_last else n - 1
         for i, blk in enumerate(self.block_seq):
@@ -629,7 +630,7 @@ class _EmbBlock(nn.Module):
                     c0 = blk.basic_block.conv
                     ho, wo = (hh + 2 * c0.pad - c0.k) // c0.stride + 1, (ww + 2 * c0.pad - c0.k) // c0.stride + 1   # shape of THIS block's output
                     pairs_next = nxt.reads_pairs_only(nn_, ho, wo)
-                x = blk(x, emb=e, emb_stride=es, in_layout=lay, out_fp32=not pairs_next)
+                x = blk(x, emb=e, emb_stride=es, in_layout=lay, out_fp32=(not pairs_next) if nxt is not None else out_fp32)
             else:
                 x = blk(x, emb=e, emb_stride=es, in_layout=in_layout if i == 0 else L.LAYOUT_NHWC)
         return x
@@ -712,9 +713,22 @@ class BasicUp(nn.Module):
 class SequentialEmb(nn.Sequential):
     """conv_blocks.py:21-25 (emb is a dict here: per-module local embeddings keyed by module id)."""
 
-    def forward(self, x, emb_lookup):
-        for m in self:
-            x = m(x, emb_lookup(m))
+    def forward(self, x, emb_lookup, out_fp32: bool = True):
+        """out_fp32=False (UNet.features): whoever reads this sequence's output reads fp16 pairs only -- forwarded to its last conv block when
+        nothing behind it in the sequence needs fp32 (an Attention that is the identity; a learnable BasicUp: a fp16-pair convolution)"""
+        mods = list(self)
+        pairs = set()
+        if not out_fp32:   # (the caller has checked that every conv block of the sequence can read pairs: UNet._pairs_only_outputs)
+            for i, m in enumerate(mods):
+                if isinstance(m, _EmbBlock):
+                    j = i + 1
+                    while j < len(mods) and not isinstance(mods[j], _EmbBlock):
+                        j += 1
+                    if all((isinstance(t, Attention) and not hasattr(t, "attention")) or (isinstance(t, BasicUp) and t.learnable and not t.use_res)
+                           for t in mods[i + 1:j]):
+                        pairs.add(id(m))
+        for m in mods:
+            x = m(x, emb_lookup(m), out_fp32=False) if id(m) in pairs else m(x, emb_lookup(m))
         return x
 
 

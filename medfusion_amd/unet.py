@@ -5,6 +5,7 @@ Same constructor arguments, `forward(x_t, t, condition, self_cond) -> (y, y_ver)
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -99,6 +100,10 @@ class UnetOutBlock(nn.Module):
         return self.conv.conv(x, out_layout=out_layout, rows=rows)
 
 
+# the conv blocks of a UNet write their outputs as fp16 pairs only wherever every reader takes pairs (UNet._pairs_only_outputs); 0: A/B switch
+PAIRS_ONLY_BLOCK_OUTPUTS = os.environ.get("MEDFUSION_PAIRS_ONLY_OUTPUTS", "1") != "0"
+
+
 class UNet(nn.Module):
     def __init__(self, in_ch=1, out_ch=1, spatial_dims=3, hid_chs=[256, 256, 512, 1024], kernel_sizes=[3, 3, 3, 3], strides=[1, 2, 2, 2],
                  act_name=("SWISH", {}), norm_name=("GROUP", {"num_groups": 32, "affine": True}), time_embedder=TimeEmbbeding,
@@ -163,6 +168,7 @@ class UNet(nn.Module):
         self._emb_cache_key = None
         self._emb_w = self._emb_b = None
         self._emb_off = {}
+        self._po_cache = {}
 
     # ------------------------------------------------------------------ embeddings
     def _packed_local_embedders(self):
@@ -311,18 +317,61 @@ class UNet(nn.Module):
             h0 = self.in_conv((a, b))
         else:
             h0 = self.in_conv(x_t, in_layout=L.LAYOUT_NCHW)
+        # Every conv block's output is read by fp16-pair convolutions, residual adds and skip concats only -- except the last one's (outc reads
+        # fp32): where that holds for the whole network (round 5; checked once per input shape, below) the blocks do not write their fp32 form
+        # at all (12 instead of 16 bytes per element behind every block: ~130 MB per evaluation at cfg2)
+        po = self._pairs_only_outputs(h0.shape)
         x = [h0]
         for blk in self.in_blocks:
-            x.append(blk(x[-1], lookup) if isinstance(blk, SequentialEmb) else blk(x[-1]))
-        h = self.middle_block(x[-1], lookup)
+            x.append(blk(x[-1], lookup, out_fp32=not po) if isinstance(blk, SequentialEmb) else blk(x[-1]))
+        h = self.middle_block(x[-1], lookup, out_fp32=not po)
         y_ver = []
         for i in range(len(self.out_blocks), 0, -1):
             hs = (h, x.pop())  # torch.cat([h, skip], 1) fused into the consumers
             depth, j = i // (self.num_res_blocks + 1), i % (self.num_res_blocks + 1) - 1
             if len(self.outc_ver) >= depth > 0 and j == 0:
                 y_ver.append(self.outc_ver[depth - 1](hs))
-            h = self.out_blocks[i - 1](hs, lookup)
+            h = self.out_blocks[i - 1](hs, lookup, out_fp32=(i == 1) or not po)
         return h, y_ver[::-1]
+
+    def _pairs_only_outputs(self, shape) -> bool:
+        """may the conv blocks skip the fp32 form of their outputs for an in_conv output of this shape?  Only when every reader is a fp16-pair
+        convolution for ITS shape: the default arithmetic, ResBlocks, no attention, no deep-supervision heads (they read fp32), learnable
+        down / up convolutions; every block asked with the shape and the skip width it will see.  Cached per shape."""
+        key = (tuple(shape), BLK.CONV_PRECISION, BLK.PAIRS_ONLY_BETWEEN_BLOCKS, PAIRS_ONLY_BLOCK_OUTPUTS)
+        ok = self._po_cache.get(key)
+        if ok is not None:
+            return ok
+        ok = (PAIRS_ONLY_BLOCK_OUTPUTS and BLK.PAIRS_ONLY_BETWEEN_BLOCKS and BLK.f16x2_mode() and self.use_res_block and len(self.outc_ver) == 0
+              and not any(hasattr(m, "attention") for m in self.modules() if isinstance(m, Attention))
+              and all(m.learnable and not m.use_res for m in self.modules() if isinstance(m, (BasicDown, BasicUp))))
+        if ok:
+            n, h, w, _ = shape
+            hw = [(h, w)]
+            widths = [shape[3]]                       # channels of x[0], x[1], ... (the skips)
+            for blk in self.in_blocks:
+                if isinstance(blk, SequentialEmb):
+                    rb = blk[0].block_seq[0]
+                    ok = ok and rb.reads_pairs_only(n, *hw[-1]) if len(widths) > 1 else ok     # (x[0] = in_conv's output has its fp32 form)
+                    widths.append(blk[0].out_channels)
+                    hw.append(hw[-1])
+                else:
+                    c = blk.down_op
+                    ok = ok and K.conv_f16x2_ok(K.make_conv_desc(n, *hw[-1], c.in_ch, 0, c.out_ch, c.k, c.stride, c.pad, 0, precision=BLK.CONV_PRECISION))
+                    widths.append(c.out_ch)
+                    hw.append(((hw[-1][0] + 2 * c.pad - c.k) // c.stride + 1, (hw[-1][1] + 2 * c.pad - c.k) // c.stride + 1))
+            cur = hw[-1]
+            ok = ok and self.middle_block[0].block_seq[0].reads_pairs_only(n, *cur) and self.middle_block[2].block_seq[0].reads_pairs_only(n, *cur)
+            for i in range(len(self.out_blocks), 0, -1):
+                seq = self.out_blocks[i - 1]
+                ok = ok and hw.pop() == cur and seq[0].block_seq[0].reads_pairs_only(n, *cur, c2=widths.pop())
+                for m in list(seq)[1:]:
+                    if isinstance(m, BasicUp):
+                        c = m.up_op
+                        ok = ok and K.conv_f16x2_ok(K.make_conv_desc(n, *cur, c.in_ch, 0, c.out_ch, 3, 1, 1, 2, precision=BLK.CONV_PRECISION))
+                        cur = (2 * cur[0], 2 * cur[1])
+        self._po_cache[key] = bool(ok)
+        return bool(ok)
 
     @torch.no_grad()
     def forward(self, x_t, t=None, condition=None, self_cond=None, emb_cache=None):

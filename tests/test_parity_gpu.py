@@ -316,6 +316,36 @@ def test_trained_like_weights_and_bound_slack(dev, conv_precision):
         assert max(v[0] for v in worst.values()) < 2.0 ** 20, worst
 
 
+def test_block_outputs_as_pairs_only(dev, conv_precision):
+    """round 5: where every reader of a conv block's output takes fp16 pairs (UNet._pairs_only_outputs: the published architecture on the
+    default arithmetic), the blocks do not write the fp32 form.  The convolutions read the same operands either way; a residual add that found
+    the fp32 form used its 24th significand bit, which the pair form does not carry (split_f16.h: at most the last bit cleared) -- so the
+    network's output moves by rounding noise, an order of magnitude below its distance to the oracle; on the other arithmetics and on models
+    that do not qualify the switch is inert (same bits)"""
+    from medfusion_amd import unet as UN
+    net = M.UNet(**to_product_kwargs(R.published_unet_kwargs(2)))
+    S.synth_state_dict(net, "pairs_only_outputs.unet.")
+    net.to(dev).eval()
+    x = S.synth_input("po_x", (4, 8, 32, 32)).to(dev)
+    t, c = torch.tensor([999, 500, 17, 0], device=dev), torch.tensor([0, 1, 1, 0], device=dev)
+    old = UN.PAIRS_ONLY_BLOCK_OUTPUTS
+    try:
+        UN.PAIRS_ONLY_BLOCK_OUTPUTS = False
+        assert not net._pairs_only_outputs((4, 32, 32, 256))
+        want = net(x, t, c)[0].clone()
+        UN.PAIRS_ONLY_BLOCK_OUTPUTS = True
+        assert net._pairs_only_outputs((4, 32, 32, 256)) == (conv_precision == 5)
+        got = net(x, t, c)[0]
+    finally:
+        UN.PAIRS_ONLY_BLOCK_OUTPUTS = old
+    e = relerr_rows(got, want)
+    print(f"[measured] pairs-only block outputs vs fp32 + pairs, arithmetic {conv_precision}: per-sample relerr {e:.2e}")
+    if conv_precision == 5:
+        assert e < 5e-7, e
+    else:
+        assert torch.equal(got, want)
+
+
 def test_progress_callback_in_every_loop_form(dev):
     """denoise(progress_cb=...): the hook where the reference drives st.progress / tqdm (diffusion_pipeline.py:289-291) -- monotone, ends at
     (total, total), same images with and without it, in the Python loop, the command-list replay and the graph replay"""
