@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512) void probe(const f16x8* __restrict__ in, float
 
 static float frand() { return (float)rand() / (float)RAND_MAX; }
 
-int main() {
+int main(int argc, char** argv) {
   constexpr int NACC = 4, THREADS = 512, BLOCKS = 256;
   const size_t n16 = (size_t)BLOCKS * THREADS * 2 * NACC * 8;
   std::vector<_Float16> h(n16);
@@ -56,6 +56,7 @@ int main() {
     }
     hipMemcpy(in, h.data(), n16 * 2, hipMemcpyHostToDevice);
     for (int iters : {400, 4000, 40000, 400000}) {   // ~25 us ... ~25 ms at full rate: does the clock hold when the burst gets long?
+      if (argc > 1 && iters != 4000) continue;
       hipLaunchKernelGGL(probe<NACC>, dim3(BLOCKS), dim3(THREADS), 0, 0, in, out, iters);   // warm-up of the same length
       hipEventRecord(e0);
       hipLaunchKernelGGL(probe<NACC>, dim3(BLOCKS), dim3(THREADS), 0, 0, in, out, iters);
@@ -64,6 +65,21 @@ int main() {
       const double flop = (double)BLOCKS * (THREADS / 64) * NACC * (double)iters * 32768.0;
       const double tf = flop / (ms * 1e-3) / 1e12;
       printf("%-58s iters %6d: %9.3f ms  %7.1f TF  = %4.1f %% of 2516.8\n", names[mode], iters, ms, tf, 100.0 * tf / 2516.8);
+    }
+  }
+  // round 6: `mfma_power_probe part` -- the same bursts (random operands, 4000 iterations) from 32 / 64 / 128 / 256 workgroups: is the ~0.62 of
+  // nominal a chip-wide budget (fewer active CUs would each run faster) or a per-CU limit (the per-CU rate stays)?
+  if (argc > 1) {
+    for (int blocks : {32, 64, 128, 192, 256}) {
+      const int iters = 4000;
+      hipLaunchKernelGGL(probe<NACC>, dim3(blocks), dim3(THREADS), 0, 0, in, out, iters);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(probe<NACC>, dim3(blocks), dim3(THREADS), 0, 0, in, out, iters);
+      hipEventRecord(e1); hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      const double flop = (double)blocks * (THREADS / 64) * NACC * (double)iters * 32768.0;
+      const double tf = flop / (ms * 1e-3) / 1e12;
+      printf("random pairs, %3d workgroups (one per CU): %9.3f ms  %7.1f TF = %4.1f %% of the nominal rate of %d CUs\n", blocks, ms, tf, 100.0 * tf / (2516.8 * blocks / 256.0), blocks);
     }
   }
   return 0;
