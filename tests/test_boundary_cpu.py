@@ -63,6 +63,36 @@ def test_struct_layouts_match_what_a_c_compiler_sees(tmp_path):
             assert int(got[f"{name}.{fname}"]) == getattr(cls, fname).offset, f"{name}.{fname}"
 
 
+def test_the_documented_level2_binding_matches_the_header(tmp_path):
+    """INTEGRATION.md's Level-2 ctypes stub, executed as written (up to its first function) against the built library and compared with the
+    header: the version it asserts is MF_VERSION, its MfConvDesc lists the header's fields in the header's order, every mf_* it binds exists
+    (the stub asserted ABI 220 while the library returned 230)"""
+    import ctypes as C
+    from medfusion_amd import lib as L
+    md = (ROOT / "INTEGRATION.md").read_text()
+    hdr = (ROOT / "include" / "medfusion_hip.h").read_text()
+    block = re.search(r"## Level 2.*?```python\n(.*?)```", md, re.S).group(1)
+    head = block.split("def conv2d_nhwc", 1)[0]
+    assert "mf_version() ==" in head and "class MfConvDesc" in head
+    L.load()
+    head = head.replace('ctypes.CDLL("libmedfusion_hip.so")', f'ctypes.CDLL({str(L.LIB_PATH)!r})')
+    ns = {}
+    exec(compile(head, "INTEGRATION.md:level2", "exec"), ns)     # its own `assert _lib.mf_version() == N` runs here
+    want = int(re.search(r"#define MF_VERSION (\d+)", hdr).group(1))
+    assert f"mf_version() == {want}" in head
+    body = re.search(r"typedef struct MfConvDesc \{(.*?)\} MfConvDesc;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    body = re.sub(r"//[^\n]*", "", body)
+    fields = [f.strip() for decl in re.findall(r"int32_t\s+([^;]+);", body) for f in decl.split(",")]
+    assert [n for n, _ in ns["MfConvDesc"]._fields_] == fields == [n for n, _ in L.MfConvDesc._fields_]
+    assert C.sizeof(ns["MfConvDesc"]) == C.sizeof(L.MfConvDesc)
+    declared = set(re.findall(r"\b(mf_[a-z0-9_]+)\s*\(", hdr))
+    live = re.sub(r"Removed \(.*?\n→", "→", md, flags=re.S)       # (the ABI history names entry points that were retired: not bindings)
+    for name in set(re.findall(r"\b(mf_[a-z0-9_]+)\b", live)):
+        ok = name in declared or (name.endswith("_") and any(d.startswith(name) for d in declared))   # `mf_cmdlist_*` style families
+        assert ok, f"INTEGRATION.md names {name}, include/medfusion_hip.h does not declare it"
+
+
 def test_host_validation_without_gpu():
     """Descriptor validation happens on the host before any launch: exercisable without a device."""
     import ctypes as C

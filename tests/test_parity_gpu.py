@@ -21,7 +21,7 @@ from medfusion_amd import kernels as K
 from oracle import restate as R
 from oracle import synth as S
 from tests.test_oracle_cpu import REFTEST_KW, SAMPLE_CASES, UNET_CASES, build_oracle_pipe
-from tests.util import T, gold, oracle_noise, relerr, relerr_rms, relerr_rows, to_product_kwargs
+from tests.util import T, gold, oracle_fp64_drift, oracle_noise, relerr, relerr_rms, relerr_rows, to_product_kwargs
 
 TOL = 1e-4
 # guided cases (classifier-free guidance 2 .. 8) on the tiny synthetic models and short trajectories of the published widths: measured on
@@ -29,8 +29,10 @@ TOL = 1e-4
 # rounds 1-2 is gone
 GUIDED_TINY_TOL = TOL
 # cold diffusion re-derives x_T from the x_0 estimate at every iteration (a division by sqrt(1 - alpha_bar), small at the first timesteps of
-# the tiny model's 4-iteration loop): measured 1.4e-4 there (same file) -- its own bound, ~3.5x the measurement
-COLD_TOL = 5e-4
+# the tiny model's 4-iteration loop): the case is ILL-CONDITIONED -- the fp32 oracle lands 1.7e-4 from its own fp64 evaluation on the DDIM
+# variant (8e-7 on the DDPM one; profiles/r06_cold_diffusion_conditioning.txt).  The test measures that drift itself (tests/util.py::
+# oracle_fp64_drift) and holds the product to max(TOL, COLD_DRIFT_FACTOR x drift): no hand-widened constant.
+COLD_DRIFT_FACTOR = 2.0
 _ORACLE_CACHE = {}
 GN32 = ("GROUP", {"num_groups": 32, "affine": True})
 GN8 = ("GROUP", {"num_groups": 8, "affine": True})
@@ -790,11 +792,12 @@ def test_cold_diffusion_through_the_loop(dev):
     ora = build_oracle_pipe(R.tiny_unet_kwargs(3, "none"), R.tiny_vae_kwargs(), "pipe_tiny")
     cond = torch.tensor([2, 0])
     for use_ddim in (True, False):
-        ora.set_noise_fn(S.PhiloxNoise(61))
+        drift = oracle_fp64_drift(ora, 61, 2, (8, 8, 8), condition=cond, guidance_scale=2.0, steps=4, use_ddim=use_ddim, cold_diffusion=True)
         want = ora.sample(2, (8, 8, 8), condition=cond, guidance_scale=2.0, steps=4, use_ddim=use_ddim, cold_diffusion=True)
         src = oracle_noise(61)
         got = pipe.sample(2, (8, 8, 8), condition=cond.to(dev), guidance_scale=2.0, steps=4, use_ddim=use_ddim, cold_diffusion=True, noise=src)
         assert src.draw_index == ora.noise_fn.draw
         e = relerr(got, want)
-        print(f"[measured] cold diffusion through the loop, ddim={use_ddim}: {e:.1e}")
-        assert e < COLD_TOL
+        bound = max(TOL, COLD_DRIFT_FACTOR * drift)
+        print(f"[measured] cold diffusion through the loop, ddim={use_ddim}: {e:.1e} (the fp32 oracle vs its fp64 self on this case: {drift:.1e}; bound {bound:.1e})")
+        assert e < bound

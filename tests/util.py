@@ -56,6 +56,33 @@ def to_product_kwargs(kw: dict) -> dict:
     return kw
 
 
+def oracle_fp64_drift(ora, seed: int, *args, **kw) -> float:
+    """How far the fp32 ORACLE lands from its own fp64 self on one sample() case: the conditioning of the case, measured.  A case whose fp32
+    evaluation is only determined to `drift` cannot be held to less by any fp32-class implementation; tests whose case is ill-conditioned
+    derive their bound from this figure instead of a hand-widened constant.  The noise fn of `ora` is left re-seeded."""
+    import copy
+
+    class _Noise64:
+        def __init__(self, s):
+            self.f = S.PhiloxNoise(s)
+
+        def __call__(self, like):
+            return self.f(like).double()
+
+    o64 = copy.deepcopy(ora).double()
+    ora.set_noise_fn(S.PhiloxNoise(seed))
+    w32 = ora.sample(*args, **kw)
+    o64.set_noise_fn(_Noise64(seed))
+    torch.set_default_dtype(torch.float64)   # (the restatement builds its sinusoidal tables / scalars in the default dtype)
+    try:
+        w64 = o64.sample(*args, **kw)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    ora.set_noise_fn(S.PhiloxNoise(seed))
+    assert w64.dtype == torch.float64
+    return relerr(w32, w64)
+
+
 def oracle_noise(seed: int):
     """HostNoise that replays the oracle's numpy-Philox draws (same draws the golden fixtures were made with)."""
     import medfusion_amd as M
