@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 230 /* 0.2.3 */
+#define MF_VERSION 240 /* 0.2.4 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -216,8 +216,9 @@ int mf_conv2d_f16x2_pairs_out(const void* x1s, const void* x2s, const void* ws, 
  * its component.  Same values as the direct form to fp32 rounding -- a DIFFERENT summation, not the same bits (error vs fp64 in
  * profiles/r05_winograd_ab.txt); MF_CONV_FP32 / MF_CONV_FP32_SPLIT3_W3 (the exact arithmetics) never take this form.
  *  mf_wino_ok(d): can `d` (3x3, stride 1, pad 1, upsample 0, NHWC, precision MF_CONV_FP32_F16X2, H and W even, C1 % 32 == C2 % 32 == 0,
- *    Cout in {64, 128, 256, 512, 1024}) run so?  mf_wino_preferred(d): ... AND did it measure faster than the direct form on MI355X for this
- *    exact shape (built-in table, csrc/wino_plan_table.inc)?
+ *    Cout in {64, 128, 256, 512, 1024}) run so?  mf_wino_preferred(d): ... AND is it the faster form on MI355X?  ABI 240: answered for ANY batch by
+ *    a rule in (Cin, Cout, H W, N) fitted to the sweeps at B = 4 ... 69 (Cin Cout >= 190 (Cin + Cout), csrc/conv_f16x2_wino.inc) instead of the
+ *    exact-shape table of ABI 230 (csrc/wino_plan_table.inc, kept as the record: mf_wino_in_table(d) says whether `d` is one of its rows).
  *  mf_wino_pack_weight_f32: OIHW 3x3 -> U = G g G^T, [16 components][Cout][Cin] fp32 (fp64 arithmetic, one rounding); split it with
  *    mf_split_f16x2(rows = 1, bound = max |U|) like any packed weight.
  *  mf_wino_input_f16x2: the fp16-pair form xs of an NHWC activation (scaled per sample by x_bound[N]) -> V = B^T d B as fp16 pairs
@@ -229,6 +230,7 @@ int mf_conv2d_f16x2_pairs_out(const void* x1s, const void* x2s, const void* ws, 
  *    d->tile_hint / splitk_hint address the component GEMM.  Two launches: the GEMM, then A^T M A + bias + statistics. */
 int mf_wino_ok(const MfConvDesc* d);
 int mf_wino_preferred(const MfConvDesc* d);
+int mf_wino_in_table(const MfConvDesc* d);
 int mf_wino_pack_weight_f32(const float* w_oihw, float* u, int Cout, int Cin, void* stream);
 int mf_wino_input_f16x2(const void* xs, const float* x_bound, void* vs, float* v_bound, int N, int H, int W, int C, void* stream);
 size_t mf_wino_workspace_bytes(const MfConvDesc* d);

@@ -543,7 +543,7 @@ class BasicResBlock(nn.Module):
         x1, x2 = _split(x)
         n, h, w, c1 = x1.shape
         c2 = 0 if x2 is None else x2.shape[-1]
-        key = (n, h, w, c1, c2, WINOGRAD)
+        key = (n, h, w, c1, c2, WINOGRAD, WINO_TAIL)
         if key in self._group:
             return self._group[key]
         ent = None
@@ -551,7 +551,10 @@ class BasicResBlock(nn.Module):
         G = nm.num_groups
         if c1 + c2 == c3.in_ch and not c3.upsample and G <= 256:
             da = K.make_conv_desc(n, h, w, c1, c2, c3.out_ch, c3.k, c3.stride, c3.pad, 0, precision=5)
-            if K.conv_f16x2_ok(da) and not wino_wanted(da):   # (a 3x3 on its Winograd form is three launches of its own: no shared launch)
+            # (a 3x3 that WILL run as Winograd component GEMM + tail has its own shared launch, _wino_guest; asked of the path that is actually taken --
+            # wino_tail_desc -- not of wino_wanted alone: a shape the tail cannot take, or MEDFUSION_WINOGRAD_TAIL=0, keeps this grouped launch.  ADVICE r05)
+            takes_wino_tail = WINO_TAIL and c3.wino_tail_desc(x, G)[1] is not None
+            if K.conv_f16x2_ok(da) and not takes_wino_tail:
                 pa = K.pin_conv_plan(da)
                 parts = K.conv_gn_parts(da, G)
                 # guest tiles of the 8-wave hosts: the one whose grid is closest to one workgroup per CU first (profiles/r04_conv_sweep_planner_vs_best.txt)

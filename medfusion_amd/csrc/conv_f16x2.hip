@@ -57,6 +57,11 @@ inline bool halo_auto() {
   static const int env = [] { const char* e = getenv("MF_CONV_HALO"); return e ? atoi(e) : 0; }();
   return env != 0;
 }
+// MF_PLAN_MODEL: 1 (default) the cost model fitted in round 6 to the sweeps at B = 8 ... 200; 0 the round-5 model (A/B, scripts/plan_model_fit.py --model old)
+inline int plan_model() {
+  static const int env = [] { const char* e = getenv("MF_PLAN_MODEL"); return e ? atoi(e) : 1; }();
+  return env;
+}
 struct PlanEntry { int N, H, W, Cin, Cout, k, stride, ups, tile, sk; };
 const PlanEntry kPlanTable[] = {
 #include "conv_plan_table.inc"
@@ -137,10 +142,25 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     double best = 1e30;
     const Tile2* bc = nullptr;
     int bsk = 1;
+    // Cost model (microseconds).  Round 6: re-fitted to EVERY sweep on file -- B = 8 / 12 / 16 / 24 / 32 / 69 / 200 at latent 32, B = 8 at latent 64,
+    // the VAE decoder at 8 / 16 / 69 / 200 (scripts/plan_model_fit.py replays it on the CPU; profiles/r06_plan_model.txt: its pick is within
+    // 0 - 2.8 % of the best of the sweep at every batch, the round-5 model was 5 - 21 % off at the batches its table does not hold):
+    //   cost = 4.4 + W (iterations + 8) t_it(tile, dense?) + 2.2 per level of the in-launch split-K tree
+    //   W    = ceil(workgroups / resident slots) for grids up to two rounds, else workgroups / slots + 0.24: a grid much larger than the chip does
+    //          not run in lock-step rounds (a CU starts its next workgroup when one retires), the last partial round costs its fraction
+    //   t_it = per-chunk time of the tile with ONE workgroup per CU (grid <= 256) / with the chip full (kTileCost: the 4-wave tiles run two per CU)
+    // The component GEMMs of the Winograd form (upsample == 3) keep the round-5 model (measured within 1-2 % of the best of their own search).
+    struct TileCost { int id; float t_sparse, t_dense; };
+    static const TileCost kTileCost[] = {{31, 1.248f, 1.332f}, {32, 1.306f, 1.341f}, {33, 0.642f, 0.677f}, {34, 0.621f, 0.667f}, {35, 0.647f, 0.762f},
+                                         {36, 0.404f, 0.709f}, {37, 0.661f, 0.835f}, {51, 0.705f, 1.225f}, {52, 0.656f, 0.673f}, {53, 0.360f, 0.675f},
+                                         {54, 0.377f, 0.686f}, {61, 1.189f, 1.215f}, {62, 1.192f, 1.234f}, {63, 0.680f, 0.685f}, {64, 0.660f, 0.691f}};
+    const bool fitted = d->upsample != 3 && plan_model() == 1;
     for (const auto& k : kTiles2) {
       if (c != nullptr && k.id != c->id) continue;   // tile already fixed
       if (c == nullptr && k.id == 52) continue;       // (A/B form of 51, never chosen automatically)
-      if (c == nullptr && k.HG && !halo_auto()) continue;
+      // halo tiles: the 256-row ones are part of the fitted model's choice (they win 1 - 8 % on the large 3x3 stride-1 shapes from B = 32 up);
+      // the 128-row ones never won a sweep and stay for explicit hints; MF_CONV_HALO=1 lets the round-5 model consider all of them
+      if (c == nullptr && k.HG && !(fitted ? (k.id == 61 || k.id == 62) : halo_auto())) continue;
       if (!valid(k)) continue;
       const long tiles = (long)cdiv(pl->M, k.BM) * (d->Cout / k.BN);
       const int percu = wgs_per_cu(k);
@@ -149,14 +169,25 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
         if (!sk_ok(s)) break;
         if (sk == 0 && !chain_ok(s) && sk_ok(s * 2) && s < 32) continue;
         const long wgs = tiles * s;
-        const long waves = (wgs + 256L * percu - 1) / (256L * percu);
         const double its = (double)cdiv(pl->cgroups, s) * pl->taps;
-        double t_it = 0.68 * k.BM * k.BN / (128.0 * 128.0);                 // 8-wave tiles, one workgroup per CU
-        if (k.BM * k.BN <= 128 * 64) t_it = (wgs > 256 ? 0.80 : 0.43);      // half-size tiles: two per CU when the grid is that large
-        else if (percu == 2) t_it = (wgs > 256 ? 1.40 : 0.75);              // 4-wave 128 x 128
-        double cost = 7.0 + waves * (its + 3.0) * t_it;
-        if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += 3.0 * lv; }   // the slices meet inside the launch
-        else if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;                          // slabs + reducer pass
+        double cost;
+        if (fitted) {
+          const double slots = 256.0 * percu;
+          double t_it = 0.68;
+          for (const auto& tc : kTileCost) if (tc.id == k.id) t_it = wgs > 256 ? tc.t_dense : tc.t_sparse;
+          const double W = wgs > 2 * slots ? wgs / slots + 0.24 : (double)((wgs + (long)slots - 1) / (long)slots);
+          cost = 4.4 + W * (its + 8.0) * t_it;
+          if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += 2.2 * lv; }
+          else if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;
+        } else {
+          const long waves = (wgs + 256L * percu - 1) / (256L * percu);
+          double t_it = 0.68 * k.BM * k.BN / (128.0 * 128.0);                 // 8-wave tiles, one workgroup per CU
+          if (k.BM * k.BN <= 128 * 64) t_it = (wgs > 256 ? 0.80 : 0.43);      // half-size tiles: two per CU when the grid is that large
+          else if (percu == 2) t_it = (wgs > 256 ? 1.40 : 0.75);              // 4-wave 128 x 128
+          cost = 7.0 + waves * (its + 3.0) * t_it;
+          if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += 3.0 * lv; }   // the slices meet inside the launch
+          else if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;                          // slabs + reducer pass
+        }
         if (cost < best) { best = cost; bc = &k; bsk = s; }
       }
     }

@@ -86,6 +86,7 @@ _SIGS = {
     "mf_conv2d_f16x2_group": (_I, [C.POINTER(MfConvF16x2Call), C.POINTER(MfConvF16x2Call), c_fp]),
     "mf_wino_ok": (_I, [C.POINTER(MfConvDesc)]),
     "mf_wino_preferred": (_I, [C.POINTER(MfConvDesc)]),
+    "mf_wino_in_table": (_I, [C.POINTER(MfConvDesc)]),
     "mf_wino_pack_weight_f32": (_I, [c_fp, c_fp, _I, _I, c_fp]),
     "mf_wino_input_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, _I, _I, _I, _I, c_fp]),
     "mf_wino_workspace_bytes": (_SZ, [C.POINTER(MfConvDesc)]),

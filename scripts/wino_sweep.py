@@ -55,6 +55,9 @@ def main():
         bconst = float(gamma.abs().max()) * (h * w_ * (co // G)) ** 0.5 + float(beta.abs().max())
         wbytes = co * cin * 9 * 4
         ncopy = max(2, -(-args.cold_mb * 1_000_000 // wbytes))
+        # every call of a timed sequence keeps its outputs alive (M workspace aside: y / pairs / the 4x transform-domain output): at B = 200 a sequence
+        # of 100 copies would not fit the device -- cap the sequence at ~30 GB of outputs (the weights of 2+ copies are cold either way at that size)
+        ncopy = max(2, min(ncopy, int(30e9 // (n * h * w_ * co * 4 * 7))))
         w0 = torch.randn((co, cin, 3, 3), generator=g) * (1.0 / (cin * 9) ** 0.5)
         whs = [K.split_weight_f16x2(K.pack_conv_weight(w0.to(dev))) for _ in range(ncopy)]
         uhs = [K.split_weight_f16x2(K.wino_pack_weight(w0.to(dev))) for _ in range(-(-ncopy * 9 // 16))]
