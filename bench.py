@@ -48,7 +48,7 @@ ARITH = {
             dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),
     5: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN> (+ its halo form conv_halo_kernel and conv_group_kernel: conv_res in the grid of its ResBlock's 3x3; the same kernel runs the component GEMMs of the Winograd form)", pmc_match=("conv_f16x2_kernel<",), terms=3, peak=PEAK_MFMA16_TFLOPS,
-            dtype="f32 (emulated: fp16 pairs, 23-bit operands)",
+            dtype="f32 (emulated: fp16 pairs -- 23-bit operands, and 23-bit STORAGE of the tensors between the UNet's conv blocks: they exist as fp16 pairs only)",
             text="fp32 EMULATED through PAIRS of fp16: every operand stored as hi + lo/2048 (23 of 24 significand bits, error <= one fp32 ulp, zero for 3 values "
                  "of 4), 3 product terms on v_mfma_f32_32x32x16_f16 (the lo*lo term is dropped), fp32 accumulate; both operands moved HBM->LDS by "
                  "LDS-DMA.  Error vs an fp64 convolution: < 3x the fp32-MFMA kernel's + 1e-6 (asserted on every test shape, "
@@ -198,13 +198,15 @@ def cpu_baseline(classes):
 def pmc_traffic(match):
     """HBM bytes per conv launch (launch-weighted average over the kernel's tile instantiations) and of its most frequent tile: PMC counters
     cannot be read live, so they come from the committed rocprofv3 passes over this same command (scripts/pmc_bench_traffic.sh ->
-    profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950)."""
+    profiles/pmc_bench_traffic.json; FETCH_SIZE doubled for gfx950).  Third value: {kernel name as rocprofv3 prints it: HBM bytes per launch} of
+    EVERY kernel of the profile (roofline.instantiations[] joins on it)."""
     try:
         pj = json.load(open(ROOT / "profiles" / "pmc_bench_traffic.json"))
         # every instantiation of the arithmetic's matrix kernels: the 9-copy kernel, the halo kernel and the grouped launches (two convolutions
         # in one grid); match[1:] narrows to the single-term instantiations where the arithmetic has its own
         names = ("conv_f16x2_kernel<", "conv_halo_kernel<", "conv_group_kernel<")
         cand = [e for e in pj["kernels"] if any(nm in e["kernel"] for nm in names) and all(m in e["kernel"] for m in match[1:])]
+        by_name = {e["kernel"]: e for e in pj["kernels"]}
         if cand:
             top = max(cand, key=lambda e: e.get("launches", 0))
             n = sum(e["launches"] for e in cand)
@@ -215,10 +217,19 @@ def pmc_traffic(match):
                               "conv_source_stamp_of_the_profile": stamp, "conv_source_stamp_now": conv_source_stamp(),
                               "stale": stamp != conv_source_stamp(),
                               "most_frequent_tile": {"kernel": top["kernel"][:80], "launches": top["launches"],
-                                                     "hbm_bytes_per_launch": top["hbm_bytes_per_launch"]}}
+                                                     "hbm_bytes_per_launch": top["hbm_bytes_per_launch"]}}, by_name
     except (OSError, KeyError, ValueError):
         pass
-    return None, None
+    return None, None, {}
+
+
+def pmc_match(by_name, kernel):
+    """the PMC entry of `kernel` (mf_prof_tag_name's spelling vs rocprofv3's: same text up to a leading `void ` and the parameter list)"""
+    norm = lambda k: k.replace("void ", "").split("(")[0].replace(" ", "")
+    for k, e in by_name.items():
+        if norm(k) == norm(kernel):
+            return e
+    return None
 
 
 def main():
@@ -329,7 +340,7 @@ def main():
         total_ms = sum(v[0] for v in tab.values())
         alg = fl / (ms * 1e-3) / 1e12     # algorithmic FLOPs of the reference convolutions / their launch time
         exe = ex / (ms * 1e-3) / 1e12     # FLOPs the matrix pipe executes: terms per product x the MACs actually done (sub-pixel up-convs: 4/9)
-        traffic, traffic_src = pmc_traffic(ar["pmc_match"])
+        traffic, traffic_src, pmc_by_name = pmc_traffic(ar["pmc_match"])
         sustained = None
         if ar["peak"] > 1000:   # the 16-bit matrix pipe: what it sustains on THIS device with nothing but MFMAs in flight, by operand data
             rnd, zer = K.mfma_sustained_tflops(dev, "random"), K.mfma_sustained_tflops(dev, "zeros")
@@ -341,14 +352,20 @@ def main():
         # profiles/*_kernel_stats.csv: launches, average duration, algorithmic and executed GFLOP per launch, executed fraction of the peak
         inst = {}
         for r in K.prof_rows("conv_igemm") + (K.prof_rows("conv_gn_fused") if "conv_gn_fused" in tab else []):
-            e = inst.setdefault(r["kernel"], dict(kernel=r["kernel"], launches=0, ms=0.0, flops=0.0, exec_flops=0.0, winograd_launches=0, winograd_ms=0.0))
-            e["launches"] += r["launches"]; e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec_flops"] += r["exec_flops"]
+            e = inst.setdefault(r["kernel"], dict(kernel=r["kernel"], launches=0, ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0, winograd_launches=0, winograd_ms=0.0))
+            e["launches"] += r["launches"]; e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["exec_flops"] += r["exec_flops"]; e["bytes"] += r["bytes"]
             if r["variant"] == 1:
                 e["winograd_launches"] += r["launches"]; e["winograd_ms"] += r["ms"]
         instantiations = [dict(kernel=e["kernel"], launches=int(e["launches"]), avg_us=round(e["ms"] / e["launches"] * 1e3, 2), total_ms=round(e["ms"], 3),
                                algorithmic_gflop_per_launch=round(e["flops"] / e["launches"] / 1e9, 3), executed_gflop_per_launch=round(e["exec_flops"] / e["launches"] / 1e9, 3),
                                algorithmic_tflops=round(e["flops"] / (e["ms"] * 1e-3) / 1e12, 1), executed_frac_of_peak=round(e["exec_flops"] / (e["ms"] * 1e-3) / 1e12 / ar["peak"], 4),
-                               winograd_component_gemm_launches=int(e["winograd_launches"]), winograd_ms=round(e["winograd_ms"], 3))
+                               winograd_component_gemm_launches=int(e["winograd_launches"]), winograd_ms=round(e["winograd_ms"], 3),
+                               # algorithmic bytes PER FORM (direct: x + w + y; Winograd component GEMM: V + U + M in the transform domain; grouped
+                               # launches: both members), the PMC bytes of the same instantiation from the committed passes, and their ratio
+                               algorithmic_bytes_per_launch=int(e["bytes"] / e["launches"]),
+                               hbm_bytes_per_launch_pmc=(pmc_match(pmc_by_name, e["kernel"]) or {}).get("hbm_bytes_per_launch"),
+                               traffic_ratio=(round(pmc_match(pmc_by_name, e["kernel"])["hbm_bytes_per_launch"] / (e["bytes"] / e["launches"]), 3)
+                                              if pmc_match(pmc_by_name, e["kernel"]) else None))
                           for e in sorted(inst.values(), key=lambda e: -e["ms"])]
         wino_ms = sum(e["winograd_ms"] for e in inst.values())
         wino_n = sum(e["winograd_launches"] for e in inst.values())
@@ -373,13 +390,17 @@ def main():
                 "algorithmic_tflops": round(alg, 2),
                 "x_over_fp32_peak_algorithmic": round(alg / PEAK_FP32_TFLOPS, 4),   # (a ratio, not a roofline fraction: the work runs on the fp16 pipe)
                 "frac_arithmetic_ceiling": round(alg / (ar["peak"] / ar["terms"]), 4),
+                "frac_note": "frac_arithmetic_ceiling credits a Winograd convolution with the flops of the 3x3 it stands for (2 M Cout 9 Cin) against the ceiling "
+                             "of the DIRECT three-term form (peak / 3): a round-over-round figure of merit, NOT a hardware fraction (it can exceed what the direct form "
+                             "could ever reach); the hardware fraction is `frac` = executed matrix flops / nominal dense fp16 peak, per instantiation in instantiations[]",
                 "arithmetic_ceiling_tflops": round(ar["peak"] / ar["terms"], 1),
                 "executed_over_algorithmic": round(ex / fl, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per conv launch, launch-weighted average over the tile instantiations (PMC)",
                 "traffic_from_committed_profile": True,   # PMC counters cannot be read inside this process: NOT measured in this run
                 "traffic_stale": None if traffic_src is None else traffic_src["stale"],   # the conv sources / tile table changed since the PMC passes
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(alg_bytes / n),   # operands read once + output written once (fp32 sizes), same average
+                "algorithmic_bytes_per_launch": int(alg_bytes / n),   # per form (see instantiations[]), launch-weighted average over the conv family
+                "traffic_ratio": None if not traffic else round(traffic / (alg_bytes / n), 3),
                 "launches": int(n), "avg_launch_ms": round(ms / n, 5), "share_of_gpu_time": round(ms / total_ms, 4),
                 "launch_timing": "every launch's own start/stop HIP events (hipExtLaunchKernel: the dispatch's execution interval, what rocprofv3 --kernel-trace "
                                  "reports; no event packets between dependent kernels -- until round 3 two hipEventRecord per launch inflated the conv family "

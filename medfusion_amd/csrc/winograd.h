@@ -212,6 +212,8 @@ struct WinoTailP {
   int N, H, W, C, G, act;
   float eps, bconst;
   int v_nt;                     // 1: the transform-domain output goes out with non-temporal stores (MF_WINO_VSTORE, A/B)
+  int xcd_map;                  // 1: consecutive groups of a sample run on ONE XCD (round 6, MF_WINO_TAIL_MAP): at 16 channels per group two groups share
+                                // every 128-byte line of M / V / the pair outputs -- with the plain (g, n) grid they sat on different XCDs (different L2s)
 };
 
 // the value a pair (hi, lo') stands for, still scaled: RN16(a) + RN16((a - RN16(a)) 2048) / 2048 -- what wino_load_pairs4 reads back
@@ -225,7 +227,15 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
   extern __shared__ __attribute__((aligned(16))) float ys[];   // [H W][cpg]
   __shared__ double sd[8];
   __shared__ float sf[8];
-  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // grid: G N workgroups, one per (sample, group).  Workgroup b runs on XCD b % 8: with xcd_map the logical index is the bijective re-numbering that
+  // gives every XCD a contiguous range of (n, g) pairs -- neighbouring groups of one sample, which share cache lines, share an L2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lin = blockIdx.x;
+  if (p.xcd_map) {
+    const int total = p.G * p.N, q = total >> 3, r = total & 7, xcd = lin & 7, within = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+  }
+  const int g = lin % p.G, n = lin / p.G;
   const int C = p.C, cpg = C / p.G, cq = cpg >> 2, c0 = g * cpg;
   const int H = p.H, W = p.W, HW = H * W, TW = W >> 1, T = (H >> 1) * TW;
   const long plane = (long)p.N * T * C;

@@ -178,6 +178,8 @@ TAIL_CASES = [
     (4, 16, 16, 64, 0, 128, 8, None, False, False, 0, True),
     (2, 32, 32, 64, 0, 256, 32, "f32", True, True, 1, True),
     (8, 8, 12, 96, 0, 128, 8, "pairs", True, True, 1, True),
+    (2, 32, 32, 64, 0, 512, 32, "pairs", True, True, 1, False),    # exactly 64 KB of dynamic LDS (1024 pixels x 16 channels): the published 512-channel tail at latent 64
+    (69, 16, 16, 128, 0, 256, 32, "pairs", False, True, 1, False),   # an odd batch: the tail chunk of the reference's bulk generator (7869 % 200)
 ]
 
 
