@@ -70,7 +70,7 @@ def main():
         print("   proxy us by (tile/split-K [workgroups]): " + " ".join(f"{t}/{s}[{w}]:{us:.1f}" for us, t, s, w in res[:14]), flush=True)
         best = res[0]
         gexec = 2.0 * 3 * n * 256 * co * kc / 1e9
-        print(f"   best proxy {best[0]:.1f} us = {gexec / best[0] / 1e3:.0f} TF executed ({gexec / best[0] / 1e3 / 2516.8:.2f} of nominal); direct {t_direct:.1f} us; "
+        print(f"   best proxy {best[0]:.1f} us = {gexec / best[0] * 1e3:.0f} TF executed ({gexec / best[0] * 1e3 / 2516.8:.2f} of nominal); direct {t_direct:.1f} us; "
               f"proxy / direct = {best[0] / t_direct:.2f}")
 
 

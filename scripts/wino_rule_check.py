@@ -21,6 +21,8 @@ def wino_rule(n, h, w, cin, co):
         return False
     if h * w >= 1024 and co >= 512 and cin * co < 300 * (cin + co) and n * h * w >= 16384:
         return False
+    if cin * co < 300 * (cin + co) and n * h * w >= 32768:
+        return False
     return True
 
 
