@@ -524,7 +524,7 @@ class BasicResBlock(nn.Module):
             m = n * h * w
             t36, t37 = -(-m // 128) * (cr.out_ch // 64), -(-m // 64) * max(cr.out_ch // 256, 1)
             order = (36, 37) if abs(t36 - 256) <= abs(t37 - 256) or cr.out_ch % 256 else (37, 36)
-            for tile in order:
+            for tile in (*order, 53):      # (53: the 4-wave guest of a 4-wave host tile -- the round-6 GEMM model picks tile 54 for 1536 -> 512 at 8 x 8)
                 if (tile == 37 and cr.out_ch % 256) or sk0 <= 0:
                     continue
                 db = K.make_conv_desc(n, h, w, c1, c2, cr.out_ch, cr.k, cr.stride, cr.pad, 0, tile_hint=tile, splitk_hint=sk0, precision=5)

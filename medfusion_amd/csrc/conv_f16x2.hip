@@ -149,12 +149,18 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
     //   W    = ceil(workgroups / resident slots) for grids up to two rounds, else workgroups / slots + 0.24: a grid much larger than the chip does
     //          not run in lock-step rounds (a CU starts its next workgroup when one retires), the last partial round costs its fraction
     //   t_it = per-chunk time of the tile with ONE workgroup per CU (grid <= 256) / with the chip full (kTileCost: the 4-wave tiles run two per CU)
-    // The component GEMMs of the Winograd form (upsample == 3) keep the round-5 model (measured within 1-2 % of the best of their own search).
+    // The component GEMMs of the Winograd form (upsample == 3: one tap, K loops of 8 - 64 chunks) take the same form with their own constants
+    // (kTileCostGemm, 9 iterations of overhead, 3.2 per tree level): a regret-minimising search over the GEMM + tail sweeps at B = 8 ... 200
+    // (profiles/r06_wino_tiles_b*.txt) -- within 0.1 - 2.5 % of the best of the search at every batch (the round-5 model: 0 - 6.7 %).
     struct TileCost { int id; float t_sparse, t_dense; };
     static const TileCost kTileCost[] = {{31, 1.248f, 1.332f}, {32, 1.306f, 1.341f}, {33, 0.642f, 0.677f}, {34, 0.621f, 0.667f}, {35, 0.647f, 0.762f},
                                          {36, 0.404f, 0.709f}, {37, 0.661f, 0.835f}, {51, 0.705f, 1.225f}, {52, 0.656f, 0.673f}, {53, 0.360f, 0.675f},
                                          {54, 0.377f, 0.686f}, {61, 1.189f, 1.215f}, {62, 1.192f, 1.234f}, {63, 0.680f, 0.685f}, {64, 0.660f, 0.691f}};
-    const bool fitted = d->upsample != 3 && plan_model() == 1;
+    static const TileCost kTileCostGemm[] = {{31, 1.160f, 1.052f}, {32, 1.306f, 1.341f}, {33, 0.596f, 0.677f}, {34, 0.621f, 0.667f}, {35, 0.647f, 0.762f},
+                                             {36, 0.404f, 0.709f}, {37, 0.630f, 0.835f}, {51, 0.705f, 1.225f}, {52, 0.656f, 0.673f}, {53, 0.381f, 0.660f},
+                                             {54, 0.377f, 0.686f}};
+    const bool fitted = plan_model() == 1, gemm = d->upsample == 3;
+    const double k_ovh = gemm ? 9.05 : 8.0, k_tree = gemm ? 3.2 : 2.2;
     for (const auto& k : kTiles2) {
       if (c != nullptr && k.id != c->id) continue;   // tile already fixed
       if (c == nullptr && k.id == 52) continue;       // (A/B form of 51, never chosen automatically)
@@ -174,10 +180,11 @@ int make_plan2(const MfConvDesc* d, Plan2* pl) {
         if (fitted) {
           const double slots = 256.0 * percu;
           double t_it = 0.68;
-          for (const auto& tc : kTileCost) if (tc.id == k.id) t_it = wgs > 256 ? tc.t_dense : tc.t_sparse;
+          if (gemm) { for (const auto& tc : kTileCostGemm) if (tc.id == k.id) t_it = wgs > 256 ? tc.t_dense : tc.t_sparse; }
+          else { for (const auto& tc : kTileCost) if (tc.id == k.id) t_it = wgs > 256 ? tc.t_dense : tc.t_sparse; }
           const double W = wgs > 2 * slots ? wgs / slots + 0.24 : (double)((wgs + (long)slots - 1) / (long)slots);
-          cost = 4.4 + W * (its + 8.0) * t_it;
-          if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += 2.2 * lv; }
+          cost = 4.4 + W * (its + k_ovh) * t_it;
+          if (s > 1 && !(s & (s - 1))) { int lv = 0; while ((1 << lv) < s) ++lv; cost += k_tree * lv; }
           else if (s > 1) cost += 4.0 + (s + 1) * (double)out_bytes / 3.5e6;
         } else {
           const long waves = (wgs + 256L * percu - 1) / (256L * percu);

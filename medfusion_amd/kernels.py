@@ -363,6 +363,11 @@ def split_of(x: torch.Tensor) -> torch.Tensor:
 
 def split_weight_f16x2(w_packed: torch.Tensor):
     """packed fp32 conv weights -> (fp16-pair form scaled by their own max, that max as a float); load-time work (one host sync)"""
+    if torch.cuda.is_current_stream_capturing():
+        # (ADVICE r05) the split needs max |w| on the HOST: a weight tensor whose first use falls inside a graph capture -- a shape first seen there
+        # -- cannot be packed; every loop form runs its first iteration eagerly for exactly this reason
+        raise RuntimeError("medfusion_amd: conv weights must be packed (a host sync) before a hipGraph capture starts: run one eager evaluation of this "
+                           "input shape first (DiffusionPipeline.denoise does: its iteration 0 is eager in every loop form)")
     w = w_packed.contiguous()
     wmax = float(w.abs().max().item())
     bound = torch.full((1,), wmax, dtype=torch.float32, device=w.device)

@@ -195,8 +195,10 @@ class DiffusionPipeline(nn.Module):
         by the reference); `eta` raises like the reference's forward() would (Q2).
         progress_cb(done, total): the hook that stands where the reference drives `st.progress` and `tqdm` (diffusion_pipeline.py:289-291; SURVEY Q16:
         no streamlit import here).  Called on the host after the iterations up to `done` have been ENQUEUED -- the loop never waits for the device;
-        a callback that wants finished iterations synchronises the stream itself.  The replayed loops (command list, graph) call it every
-        max(1, total // 20) iterations; the Python loop every iteration."""
+        a callback that wants finished iterations synchronises the stream itself.  The replayed loops (command list, graph) call it after the eager
+        first iteration, then every max(1, total // 20) iterations; the Python loop every iteration.  The counts a caller sees are STRICTLY
+        INCREASING: when the loop has to be re-run (a fused rendezvous timed out, K.with_fused_fallback) the counts already reported are not
+        reported again."""
         if not x_t.is_cuda:
             raise RuntimeError("medfusion_amd.DiffusionPipeline runs on a ROCm device only (no CPU fallback)")
         with torch.cuda.device(x_t.device):   # (see sample())
@@ -213,6 +215,14 @@ class DiffusionPipeline(nn.Module):
                     raise RuntimeError("medfusion_amd: the sampling loop must be re-run on the two-launch GroupNorm form, but its host noise source "
                                        "cannot be rewound: set MEDFUSION_FUSED_APPLY=0 when several processes share one GPU")
                 noise.draw_index = draws0
+
+            if progress_cb is not None:
+                user_cb, reported = progress_cb, [0]
+
+                def progress_cb(done, total):   # monotone across a re-run of the loop
+                    if done > reported[0]:
+                        reported[0] = done
+                        user_cb(done, total)
 
             return K.with_fused_fallback(x_t.device, lambda: self._denoise(x_t, steps, condition, use_ddim, noise, trace, decode, use_graph, loop, progress_cb,
                                                                            **dict(kwargs)), rewind)
@@ -409,6 +419,8 @@ class DiffusionPipeline(nn.Module):
             lib = L.load()
             cur = K.stream(dev.index)
             first_iteration()
+            if progress_cb is not None:
+                progress_cb(1, len(rev))
             if len(rev) > 1:
                 pool = _CMD_POOLS.get((dev.index, cur))    # one pool per (device, stream): two threads driving two streams record independently
                 if pool is None:
@@ -474,6 +486,8 @@ class DiffusionPipeline(nn.Module):
         with torch.cuda.stream(side):
             K.SyncWords.reset(dev)    # (the counters of THIS stream: _denoise reset those of the caller's stream)
             first_iteration()
+            if progress_cb is not None:
+                progress_cb(1, len(rev))
             done = 1
             if len(rev) > done:
                 graph = torch.cuda.CUDAGraph()

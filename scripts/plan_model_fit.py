@@ -49,6 +49,8 @@ def halo_fits(shape, t):
 
 def geometry(shape):
     N, H, W, Cin, Cout, k, st, ups = shape
+    if ups == 3:                                     # the component GEMMs of a Winograd convolution: N = 16 x batch pseudo-samples of H W = T tile rows, 1x1
+        return N * H * W, 1, Cin // 32
     if ups == 2:
         return N * 4 * H * W, 4, Cin // 32          # sub-pixel: M over (n, phase, y, x), 4 taps
     Ho = (H + 2 * (1 if k == 3 else 0) - k) // st + 1
@@ -62,7 +64,7 @@ def candidates(shape, halo_auto=False):
         BM, BN = t[0], t[1]
         if tid == 52 or (t[5] and not halo_auto):
             continue
-        if Cout % BN or (ups == 2 and (H * W) % BM) or not halo_fits(shape, t):
+        if Cout % BN or (ups == 2 and (H * W) % BM) or (ups == 3 and ((N // 16) * H * W) % BM) or not halo_fits(shape, t):
             continue
         s = 1
         while s <= 32 and s <= cg:
@@ -100,18 +102,24 @@ TILE_COST = {31: (1.248, 1.332), 32: (1.306, 1.341), 33: (0.642, 0.677), 34: (0.
              64: (0.660, 0.691)}
 
 
+# the component GEMMs (upsample == 3): the same form, constants from a regret-minimising search over profiles/r06_wino_tiles_b*.txt
+TILE_COST_GEMM = {31: (1.160, 1.052), 32: (1.306, 1.341), 33: (0.596, 0.677), 34: (0.621, 0.667), 35: (0.647, 0.762), 36: (0.404, 0.709), 37: (0.630, 0.835),
+                  51: (0.705, 1.225), 52: (0.656, 0.673), 53: (0.381, 0.660), 54: (0.377, 0.686)}
+
+
 def cost_new(shape, tid, s, P=None):
     t = TILES[tid]
     BM, BN = t[0], t[1]
     M, taps, cg = geometry(shape)
+    gemm = shape[7] == 3
     wgs = -(-M // BM) * (shape[4] // BN) * s
     slots = 256 * percu(t)
     its = -(-cg // s) * taps
-    t_it = TILE_COST[tid][1 if wgs > 256 else 0]
+    t_it = (TILE_COST_GEMM if gemm else TILE_COST)[tid][1 if wgs > 256 else 0]
     W = wgs / slots + 0.24 if wgs > 2 * slots else -(-wgs // slots)
-    c = 4.4 + W * (its + 8.0) * t_it
+    c = 4.4 + W * (its + (9.05 if gemm else 8.0)) * t_it
     if s > 1:
-        c += 2.2 * int(math.log2(s))
+        c += (3.2 if gemm else 2.2) * int(math.log2(s))
     return c
 
 
@@ -141,6 +149,35 @@ def regret(path, batch, latent, model="new"):
         tp += cnt * times.get(pick, max(max(times.values()), t_auto))
         tb += cnt * min(times.values())
     return tp, tb
+
+
+# scripts/wino_sweep.py --tiles: GEMM + tail time of every Winograd-capable 3x3 by the component GEMM's (tile, split-K); "0/0" = the planner's own pick
+WINO_TILE_SWEEPS = [(f"profiles/r06_wino_tiles_b{b}.txt", b, 32) for b in (8, 12, 16, 24, 32, 69, 200)]
+
+
+def parse_wino_tiles(path, batch, latent=32):
+    f = latent // 32
+    dims = {nm: ((16 * n, 1, (h * f // 2) * (w * f // 2), c1 + c2, co, 1, 1, 3), cnt) for nm, n, h, w, c1, c2, co, k, st, ups, cnt in unet_shapes(batch) if k == 3 and st == 1 and not ups}
+    rows, last = [], None
+    for ln in Path(path).read_text().splitlines():
+        m = re.match(r"(\S.*?\.c[01])\s+[\d.]+ \|", ln)
+        if m:
+            last = m.group(1).strip()
+            continue
+        if last and "GEMM + tail, us by (tile, split-K):" in ln:
+            times = {(int(a), int(b)): float(c) for a, b, c in re.findall(r"(\d+)/(\d+):([\d.]+)", ln)}
+            auto = times.pop((0, 0), None)
+            shape, cnt = dims[last]
+            rows.append((last, shape, cnt, auto if auto is not None else min(times.values()), times))
+            last = None
+    return rows
+
+
+def gemm_model_pick(shape, model="new"):
+    """the component GEMM's (tile, split-K) by the cost model: candidates as make_plan2 admits them for upsample == 3 (no halo tiles; the split-K must
+    meet inside the launch: powers of two)"""
+    cands = [c for c in candidates(shape) if TILES[c[0]][5] == 0]
+    return min(cands, key=lambda c: (cost_new if model == "new" else cost_old)(shape, c[0], c[1]))
 
 
 def parse(path, batch, latent=32, vae_batch=None):
@@ -189,5 +226,23 @@ def main():
               f"pick / best {tot_pick / tot_best:.3f}  ({unknown} picks outside the sweep's top 8: priced at the 8th)")
 
 
+def main_gemm(model):
+    print("component GEMMs of the Winograd form (GEMM + tail, us per UNet evaluation; a pick outside the sweep's top 10 is priced at the 10th):")
+    for path, B, lat in WINO_TILE_SWEEPS:
+        if not (ROOT / path).exists():
+            continue
+        tp = tb = ta = 0.0
+        miss = 0
+        for nm, shape, cnt, t_auto, times in parse_wino_tiles(ROOT / path, B, lat):
+            pick = gemm_model_pick(shape, model)
+            if pick not in times:
+                miss += 1
+            tp += cnt * times.get(pick, max(max(times.values()), t_auto))
+            tb += cnt * min(times.values())
+            ta += cnt * t_auto
+        print(f"{Path(path).name:40s} B={B:3d}: planner at sweep time {ta:8.1f} | model({model}) pick {tp:8.1f} | best {tb:8.1f} | pick / best {tp / tb:.3f} ({miss} outside the list)")
+
+
 if __name__ == "__main__":
     main()
+    main_gemm("old" if "--model" in sys.argv and "old" in sys.argv else "new")

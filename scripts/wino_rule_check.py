@@ -12,16 +12,16 @@ from conv_sweep import unet_shapes  # noqa: E402
 # (file, batch, latent)
 SWEEPS = [("profiles/r05_wino_sweep_b4.txt", 4, 32), ("profiles/r05_wino_sweep_b8.txt", 8, 32), ("profiles/r05_wino_sweep_b16.txt", 16, 32),
           ("profiles/r05_wino_sweep_b32.txt", 32, 32), ("profiles/r05_wino_sweep_l64.txt", 8, 64), ("profiles/r05_wino_sweep_b16_l64.txt", 16, 64),
-          ("profiles/r06_wino_sweep_b12.txt", 12, 32), ("profiles/r06_wino_sweep_b24.txt", 24, 32), ("profiles/r06_wino_sweep_b69.txt", 69, 32),
-          ("profiles/r06_wino_sweep_b200.txt", 200, 32)]
+          # round 6, on the round-6 planner, the component GEMM on the best (tile, split-K) of its search (what the round-6 GEMM model picks to 0 - 2.5 %)
+          ("profiles/r06_wino_tiles_b8.txt", 8, 32), ("profiles/r06_wino_tiles_b12.txt", 12, 32), ("profiles/r06_wino_tiles_b16.txt", 16, 32),
+          ("profiles/r06_wino_tiles_b24.txt", 24, 32), ("profiles/r06_wino_tiles_b32.txt", 32, 32), ("profiles/r06_wino_tiles_b69.txt", 69, 32),
+          ("profiles/r06_wino_tiles_b200.txt", 200, 32)]
 
 
 def wino_rule(n, h, w, cin, co):
     if cin * co < 190 * (cin + co):
         return False
     if h * w >= 1024 and co >= 512 and cin * co < 300 * (cin + co) and n * h * w >= 16384:
-        return False
-    if cin * co < 300 * (cin + co) and n * h * w >= 32768:
         return False
     return True
 

@@ -360,6 +360,24 @@ def test_progress_callback_in_every_loop_form(dev):
         assert seen and seen[-1] == (25, 25) and all(t == 25 for _, t in seen), (loop, seen)
         assert [d for d, _ in seen] == sorted(set(d for d, _ in seen)), (loop, seen)
         assert len(seen) == 25 if loop == "eager" else len(seen) >= 20, (loop, len(seen))
+        assert seen[0] == (1, 25), (loop, seen[:3])      # the eager first iteration of the replayed loops is reported too
+    # a loop that is re-run after a fused rendezvous fault (K.with_fused_fallback: rewind + second pass) never reports a count twice
+    from medfusion_amd import kernels as K
+    orig = K.with_fused_fallback
+
+    def twice(device, fn, rewind=None):
+        fn()
+        if rewind is not None:
+            rewind()
+        return fn()
+    K.with_fused_fallback = twice
+    try:
+        seen = []
+        c = pipe.sample(2, (8, 8, 8), steps=25, noise=M.PhiloxDeviceNoise(5), loop="eager", progress_cb=lambda done, total: seen.append(done))
+    finally:
+        K.with_fused_fallback = orig
+    assert seen == list(range(1, 26)), seen
+    assert torch.equal(c, b)
 
 
 @pytest.fixture(scope="module")

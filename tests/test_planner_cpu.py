@@ -389,7 +389,7 @@ def test_conv_res_finds_its_place_in_the_component_gemm_launch():
         x = x1 if not c2 else (x1, torch.empty((n, h, w, c2), device="meta"))
         g = blk._wino_guest(x)
         assert g is not None, (n, h, w, c1, c2, co)
-        assert K.conv_plan(g[0])[0] in (36, 37) and g[1][1] > 0      # an 8-wave guest tile; its output is measured (bound slots)
+        assert K.conv_plan(g[0])[0] in (36, 37, 53) and g[1][1] > 0  # a guest tile with the host's workgroup size; its output is measured (bound slots)
         assert blk._grouped(x) is None                                # (the direct form's grouped launch steps aside)
 
 
