@@ -184,10 +184,7 @@ def parse(path, batch, latent=32, vae_batch=None):
     shapes = {}
     f = latent // 32
     for nm, n, h, w, c1, c2, co, k, st, ups, cnt in unet_shapes(batch) + vae_shapes(vae_batch or batch):
-        if nm.startswith("vae"):
-            shapes[nm] = ((n, h, w, c1 + c2, co, k, st, 2 if ups else 0), cnt)
-        else:
-            shapes[nm] = ((n, h * f, w * f, c1 + c2, co, k, st, 2 if ups else 0), cnt)
+        shapes[nm] = ((n, h * f, w * f, c1 + c2, co, k, st, 2 if ups else 0), cnt)     # (conv_sweep.py --latent scales every shape, the VAE's too)
     rows = []
     for ln in Path(path).read_text().splitlines():
         m = re.match(r"(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+([\d.]+) \|\s+([\d.]+)\s+[\d.]+ \| \((\d+),(\d+)\) ([\d.]+)\s+[\d.]+ \| (.*)$", ln)

@@ -39,6 +39,7 @@ if __name__ == "__main__":
     ap.add_argument("--out", default="generated_diffusion3")
     ap.add_argument("--no-files", action="store_true", help="run the egress (device conversion + async copy) but skip the PNG encoder")
     ap.add_argument("--compare-no-egress", action="store_true", help="also time the same generation with the images left on the device")
+    ap.add_argument("--writer-threads", type=int, default=2, help="PNG encoder threads of the asynchronous writer")
     args = ap.parse_args()
 
     device = torch.device("cuda")
@@ -59,7 +60,7 @@ if __name__ == "__main__":
                 path_out = Path(f"{args.out}_{steps}") / name
                 if egress and not args.no_files:
                     path_out.mkdir(parents=True, exist_ok=True)
-                writer = AsyncImageWriter(device, sink=None if args.no_files else save_png) if egress else None
+                writer = AsyncImageWriter(device, sink=None if args.no_files else save_png, threads=args.writer_threads) if egress else None
                 torch.manual_seed(0)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -77,4 +78,8 @@ if __name__ == "__main__":
                 t_all += time.perf_counter() - t0
                 total += counter
         stats["with_egress" if egress else "images_left_on_device"] = {"images": total, "seconds": round(t_all, 3), "images_per_s": round(total / t_all, 3)}
-    print(json.dumps({"bulk_generation": stats, "sample_batch": args.sample_batch, "guidance_scale": cfg}))
+    out = {"bulk_generation": stats, "sample_batch": args.sample_batch, "guidance_scale": cfg, "n_samples_per_class": args.n_samples, "steps": args.steps_list,
+           "png_files_written": not args.no_files, "writer_threads": args.writer_threads}
+    if "with_egress" in stats and "images_left_on_device" in stats:
+        out["egress_overlap"] = round(stats["with_egress"]["images_per_s"] / stats["images_left_on_device"]["images_per_s"], 4)   # 1.0 = the egress is free
+    print(json.dumps(out))

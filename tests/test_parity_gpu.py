@@ -773,6 +773,37 @@ def test_cfg2_rows_of_the_benchmarked_batch_vs_oracle(dev, conv_precision):
     assert max(rms) < TOL and relerr_rms(got[rows], want) < TOL
 
 
+@torch.no_grad()
+def test_bulk_tail_chunk_of_69_rows_vs_oracle(dev, conv_precision):
+    """The reference's bulk generator samples 7869 images per class in chunks of 200: its last chunk has 69 rows (scripts/helpers/sample_dataset.py:
+    26-27,38).  No plan table holds B = 69 or B = 200: the planner's cost model and the Winograd rule decide (round 6).  69 unconditional samples at
+    latent (8,32,32), device Philox noise, 12 DDIM iterations + decode; rows 0, 33 and 68 against the oracle fed the SAME global Philox rows --
+    the odd batch also exercises the partial last tiles of the direct form (69 x 64 = 4416 = 34.5 x 128 rows at the 8 x 8 level, where the component
+    GEMMs' tiles do not divide a component and the convolutions stay direct) next to the Winograd form at the 16 x 16 level."""
+    if conv_precision != 5:
+        pytest.skip("the default arithmetic (the batch-general plan rule is its planner's)")
+    from medfusion_amd import published as P
+    from medfusion_amd import blocks as BLK
+    pipe = P.build_published_pipeline(dev, num_classes=None)
+    ora = build_oracle_pipe(R.published_unet_kwargs(None), R.published_vae_kwargs(8), "published")
+    rows = [0, 33, 68]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    nz = S.PhiloxNoise(6900)
+    ora.set_noise_fn(lambda like: nz(torch.empty((69, *like.shape[1:])))[rows])
+    tr_o, tr_p = [], []
+    want = ora.sample(3, (8, 32, 32), steps=12, use_ddim=True, trace=tr_o)
+    got = pipe.sample(69, (8, 32, 32), steps=12, use_ddim=True, noise=M.PhiloxDeviceNoise(6900), trace=tr_p)
+    assert got.shape == (69, 3, 256, 256)
+    errs = [relerr_rows(tr_p[i][0][rows], tr_o[i][0]) for i in range(0, 12, 3)] + [relerr_rows(tr_p[-1][1][rows], tr_o[-1][1])]
+    e_img, e_rms = relerr_rows(got[rows], want), relerr_rms(got[rows], want)
+    d16, d8 = K.make_conv_desc(69, 16, 16, 512, 0, 512, 3, 1, 1, 0, precision=5), K.make_conv_desc(69, 8, 8, 1024, 0, 1024, 3, 1, 1, 0, precision=5)
+    print(f"[measured] B = 69 (bulk tail chunk), rows {rows}: x0 per-sample rel-err every 3 iterations + final latents: " + " ".join(f"{e:.1e}" for e in errs) +
+          f" | images {e_img:.1e} (RMS-relative {e_rms:.1e}) | Winograd form at 16 x 16: {K.wino_preferred(d16)}, at 8 x 8: {K.wino_preferred(d8)} "
+          f"| direct plan of 512 -> 512 @16^2: {K.conv_plan(d16)}")
+    assert K.wino_preferred(d16) and not K.wino_ok(d8)
+    assert max(errs) < TOL and e_img < TOL and e_rms < TOL
+
+
 F16_TOL = 1e-2
 
 
