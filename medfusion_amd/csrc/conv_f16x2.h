@@ -92,6 +92,7 @@ struct ConvP2 {
   int subpix, hw_src;
   int out_nt;            // 1: non-temporal output stores (the component GEMM's output is 4x an activation, read once by the tail)
   int wphase_rows;       // > 0: rows [k wphase_rows, (k + 1) wphase_rows) of the GEMM use weight slab k (the component GEMMs of the Winograd form, winograd.h)
+  int walk_n_fast;       // 1: the tile walk runs over the output-channel tiles first (an XCD covers all Cout blocks of a pixel range: activations fetched once)
   double* gn_partial;   // optional fused GroupNorm statistics [N][gn_parts][G][2] (splitk == 1, or tree)
   int gn_groups, gn_parts, gn_cpg;
   // split-K reduced INSIDE the launch (tree != 0, splitk a power of two): the partial tiles meet pairwise, level by level; at every level

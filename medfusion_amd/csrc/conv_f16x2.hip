@@ -571,6 +571,14 @@ static int conv_f16x2_prepare(const void* x1s, const void* x2s, const void* ws, 
   p.bytes2 = (unsigned)(4.0 * d->N * d->Hin * d->Win * d->C2);
   p.bytesw = (unsigned)(4.0 * d->Cout * pl.K * (p.subpix ? 4 : wino_gemm ? 16 : 1));
   p.wphase_rows = wino_gemm ? (d->N / 16) * d->Hin * d->Win : 0;
+  {
+    // tile walk (round 6): output-channel tiles fastest where the activations outweigh the weights -- every XCD then covers all Cout blocks of ITS
+    // pixel range and the activation tensor is fetched once instead of tiles_n times (the weights are then fetched by every XCD: the smaller operand).
+    // MF_CONV_WALK: 0 the round-5 pixel-fastest walk everywhere (A/B), 1 (default) by operand size, 2 output-channel-fastest everywhere.
+    static const int walk = [] { const char* e = getenv("MF_CONV_WALK"); return e ? atoi(e) : 1; }();
+    const double act_bytes = 4.0 * d->N * d->Hin * d->Win * (d->C1 + d->C2), w_bytes = 4.0 * d->Cout * pl.K * (p.subpix ? 4 : 1);
+    p.walk_n_fast = (!wino_gemm && p.tiles_n > 1 && (walk == 2 || (walk == 1 && act_bytes > w_bytes))) ? 1 : 0;
+  }
   p.out_nt = 0;   // (non-temporal stores for the component GEMM's output: 397.54 vs 397.53 ms on the cfg2 step -- nothing; the hook stays for A/B builds)
   p.gn_partial = nullptr; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 8; p.gn_parts = 0;
   p.tree = 0; p.handoff = nullptr; p.sync = nullptr;
