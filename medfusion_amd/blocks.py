@@ -135,8 +135,9 @@ SUBPIXEL_UPSAMPLE = True  # BasicUp as the sub-pixel (transposed-conv-equivalent
 #   6 opt-in REDUCED precision on the LDS-DMA kernel of 5: the same fp16-pair operands, ONE product term (operands rounded to fp16, 11 bits;
 #     MF_CONV_F16) -- its own tolerance, never a default, never the headline.
 CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "5"))
-# Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolutions (arithmetic 5 only; kernels.conv2d_wino_f16x2): 0 never, 1 (default) the shapes of
-# csrc/wino_plan_table.inc -- those it measured faster on -- 2 wherever the library can (tests, sweeps).  Read per call like CONV_PRECISION.
+# Winograd F(2x2, 3x3) form of the 3x3 stride-1 convolutions (arithmetic 5 only; kernels.conv2d_wino_f16x2): 0 never, 1 (default) where the library
+# prefers it (mf_wino_preferred: a rule fitted to the MI355X sweeps that holds at any batch, round 6; it admits every shape of csrc/wino_plan_table.inc),
+# 2 wherever the library can (tests, sweeps).  Read per call like CONV_PRECISION.
 WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
 
 
@@ -189,7 +190,7 @@ class Conv(nn.Module):
             pinned = K.pin_conv_plan(d) if ok else None     # (tile, split-K) fixed in the descriptor: per-launch planning is a field read
             wino = None
             if ok and prec == 5 and not cin_pad and self.k == 3 and wino_wanted(d):
-                # the Winograd form measured faster for this exact shape (csrc/wino_plan_table.inc): 2.25x fewer matrix instructions
+                # the Winograd form is the faster one for this shape (mf_wino_preferred): 2.25x fewer matrix instructions
                 wparts = K.wino_gn_parts(d, gn_groups) if gn_groups else 0
                 if not gn_groups or wparts > 0:
                     wt, wsk = WINO_SHAPES.get((n, h, w, c1 + c2, self.out_ch), (0, 0))

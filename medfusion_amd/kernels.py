@@ -530,7 +530,8 @@ def wino_ok(d: L.MfConvDesc) -> bool:
 
 
 def wino_preferred(d: L.MfConvDesc) -> bool:
-    """did the Winograd form measure faster than the direct form for this exact shape (csrc/wino_plan_table.inc; MF_WINO=0/1/2)?"""
+    """is the Winograd form the faster one for `d` on MI355X?  (mf_wino_preferred: since ABI 240 a rule in (Cin, Cout, H W, N) that holds at any batch --
+    csrc/conv_f16x2_wino.inc; the host switch is blocks.WINOGRAD / MEDFUSION_WINOGRAD = 0 never | 1 where preferred | 2 wherever mf_wino_ok)"""
     return bool(L.load().mf_wino_preferred(C.byref(d)))
 
 
