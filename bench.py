@@ -37,6 +37,9 @@ WORKLOADS = {
     "cfg3_g8": dict(batch=16, latent=(8, 32, 32), steps=150, use_ddim=True, classes=3, guidance=8.0),
     "cfg4": dict(batch=8, latent=(8, 32, 32), steps=1000, use_ddim=False, classes=None, guidance=1.0),
     "cfg5": dict(batch=8, latent=(8, 64, 64), steps=150, use_ddim=True, classes=None, guidance=1.0),
+    # not a BASELINE config: the chunk the reference's own bulk generator samples at (scripts/helpers/sample_dataset.py:26-27,38: 200 images per call, 2-class
+    # condition, guidance 1) -- no plan table holds this batch, the planner's cost model and the Winograd rule decide (round 6)
+    "bulk200": dict(batch=200, latent=(8, 32, 32), steps=150, use_ddim=True, classes=2, guidance=1.0),
 }
 ARITH = {
     0: dict(kernel="conv_igemm_kernel<..., MODE 0>", pmc_match=("conv_igemm_kernel<", ", 0, "), terms=1, peak=PEAK_FP32_TFLOPS, dtype="f32",
@@ -434,7 +437,7 @@ def main():
         # every other BASELINE.json config at its per-GPU size, in THIS process and on the default arithmetic: a warm-up
         # (short for cfg4: its loop is the 1000-iteration one), then the timed steps, fenced like the headline.  ~15 s in all.
         pipes = {None: pipe}
-        for name, nsteps in (("cfg3_g1", 2), ("cfg3_g8", 2), ("cfg5", 2), ("cfg4", 1)):
+        for name, nsteps in (("cfg3_g1", 2), ("cfg3_g8", 2), ("cfg5", 2), ("cfg4", 1), ("bulk200", 1)):
             w2 = WORKLOADS[name]
             if w2["classes"] not in pipes:
                 pipes[w2["classes"]] = P.build_published_pipeline(dev, w2["classes"])
@@ -444,7 +447,7 @@ def main():
             if c2 is not None:
                 k2.update(guidance_scale=w2["guidance"], un_cond=None)
             p2.sample(w2["batch"], w2["latent"], condition=c2, noise=M.PhiloxDeviceNoise(3000), steps=min(w2["steps"], 20), **k2)   # warm-up
-            if name != "cfg4":
+            if name not in ("cfg4", "bulk200"):
                 p2.sample(w2["batch"], w2["latent"], condition=c2, noise=M.PhiloxDeviceNoise(3001), steps=w2["steps"], **k2)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -458,7 +461,8 @@ def main():
                                                      f"iterations, {'uncond' if c2 is None else 'cond %d-class g=%s' % (w2['classes'], w2['guidance'])}, decode to "
                                                      f"{8 * w2['latent'][1]}x{8 * w2['latent'][2]}", "n_gpus": 1,
                                          "baseline_config": {"cfg3_g1": "configs[2] per-GPU share (128 / 8), guidance 1", "cfg3_g8": "configs[2] per-GPU share, guidance 8 (2B-row UNet calls)",
-                                                             "cfg4": "configs[3]", "cfg5": "configs[4] per-GPU share (32 / 4)"}[name]}})
+                                                             "cfg4": "configs[3]", "cfg5": "configs[4] per-GPU share (32 / 4)",
+                                                             "bulk200": "none -- the reference's bulk harness chunk (scripts/helpers/sample_dataset.py:26-27), a batch outside every plan table"}[name]}})
         del pipes
     cpu = parity = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
