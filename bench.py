@@ -58,7 +58,7 @@ ARITH = {
                  "tests/test_kernels_gpu.py::test_conv_f16x2), 0.4-2.1x measured (profiles/r02_split_accuracy.txt, profiles/r04_parity_measured.txt); not "
                  "bit-width-equal to fp32 -- the exact-operand arithmetics are timed in the same run (other_conv_arithmetic).  Round 5: the 3x3 stride-1 "
                  "convolutions of the 8 x 8 and 16 x 16 levels run in their Winograd F(2x2,3x3) form on this arithmetic (16 component GEMMs on the same "
-                 "kernel, 2.25x fewer matrix instructions; csrc/wino_plan_table.inc; error vs fp64 at or below the direct form's, profiles/r05_winograd_ab.txt)"),
+                 "kernel, 2.25x fewer matrix instructions; which shapes: mf_wino_preferred, a rule since round 6; error vs fp64 at or below the direct form's, profiles/r05_winograd_ab.txt)"),
     6: dict(kernel="conv_f16x2_kernel<BM, BN, WM, WN, NST, 1>", pmc_match=("conv_f16x2_kernel<", ", 1>"), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="f16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision on the LDS-DMA kernel: conv operands rounded to fp16 (11 significant bits, per-sample power-of-two scales), one MFMA "
@@ -386,7 +386,7 @@ def main():
                            "round-over-round figure)",
                 "winograd": {"component_gemm_launches": int(wino_n), "ms": round(wino_ms, 3), "share_of_conv_time": round(wino_ms / ms, 4),
                              "tail_and_transform_ms": round(tab["wino_xform"][0], 3) if "wino_xform" in tab else 0.0,
-                             "what": "3x3 stride-1 convolutions of csrc/wino_plan_table.inc as 16 component GEMMs on the same kernel (algorithmic flops: the "
+                             "what": "3x3 stride-1 convolutions mf_wino_preferred admits (a rule in Cin, Cout, H W, N since ABI 240; it reproduces csrc/wino_plan_table.inc) as 16 component GEMMs on the same kernel (algorithmic flops: the "
                                      "convolution's own 2 M Cout 9 Cin; executed: 3 terms x 2 (4 M / 4) Cout Cin); their output transform + GroupNorm + Swish + "
                                      "residual + next input transform is ONE tail launch each (family wino_xform, an HBM-bound pass: hbm_bound_passes)"},
                 "instantiations": instantiations,
