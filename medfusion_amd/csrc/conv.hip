@@ -216,6 +216,98 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const ConvP p, int g
   }
 }
 
+// Round 6: the same convolution, the same fma chain per output (bias, then k = 0 .. K-1 in order: BIT-IDENTICAL results), with the two parts of the
+// kernel above that were not arithmetic taken out of its critical path (27.7 us per launch for 0.6 GFLOP at the UNet's in_conv, B = 16):
+//   * the im2col patch was filled element by element with six integer divisions by run-time values per element (~ 200 instructions x 18 elements
+//     per thread).  Here a thread owns ONE pixel of the group (its coordinates: two divisions per group) and walks k in steps of 4 through a
+//     table of (ky, kx, ci) built once per workgroup;
+//   * the patch is laid out [k][pixel] instead of [pixel][k]: the inner loop reads the 16 pixel values of a k as four 16-byte LDS broadcasts
+//     instead of sixteen 4-byte ones (5 LDS instructions per 64 fmas instead of 17).
+// MF_SMALLCIN=0 launches the round-5 kernel (A/B and the bit-equality test).
+__global__ __launch_bounds__(256) void conv_smallcin2_kernel(const ConvP p, int groups) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wT = sm;                                                  // [K][kSmallCo]
+  float* patch = sm + (size_t)p.K * kSmallCo;                      // [kSmallPG][K][kSmallPix]
+  int* ktab = reinterpret_cast<int*>(patch + (size_t)kSmallPG * kSmallPix * p.K);   // [K]: ky | kx << 8 | ci << 16
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * kSmallCo;
+  const int nco = min(kSmallCo, p.Cout - co0);
+  if (tid < nco) {
+    const float* wr = p.w + (long)(co0 + tid) * p.K;
+    for (int k = 0; k < p.K; ++k) wT[k * kSmallCo + tid] = wr[k];
+  }
+  if (tid < p.K) {
+    const int tap = tid / p.Cin, ci = tid - tap * p.Cin;
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    ktab[tid] = ky | (kx << 8) | (ci << 16);
+  }
+  const int pg = tid >> 6, cq = tid & 63;
+  const bool active = cq * 4 < nco;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active && p.bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = p.bias[co0 + cq * 4 + j];
+  }
+  const int fpx = tid >> 2, fk0 = tid & 3;            // fill: pixel 0 .. 63 of the 4 x 16 pixels of an iteration, first k
+  const int fgq = fpx >> 4, fq = fpx & 15;
+  for (int g0 = blockIdx.x * kSmallPG; g0 < groups; g0 += gridDim.x * kSmallPG) {
+    __syncthreads();
+    {
+      const int m = (g0 + fgq) * kSmallPix + fq;
+      const bool inside = m < p.M;
+      int n = 0, iy0 = 0, ix0 = 0;
+      if (inside) {
+        n = m / p.HWout;
+        const int rem = m - n * p.HWout;
+        const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+        iy0 = oy * p.stride - p.pad;
+        ix0 = ox * p.stride - p.pad;
+      }
+      float* dst = patch + (size_t)fgq * kSmallPix * p.K + fq;
+      for (int k = fk0; k < p.K; k += 4) {
+        const int e = ktab[k];
+        const int iy = iy0 + (e & 255), ix = ix0 + ((e >> 8) & 255), ci = e >> 16;
+        float v = 0.f;
+        if (inside && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff) {
+          const int sy = iy >> p.ups, sx = ix >> p.ups;
+          v = p.in_nchw ? p.x1[((long)(n * p.C1 + ci) * p.Hin + sy) * p.Win + sx]
+                        : (ci < p.C1 ? p.x1[((long)(n * p.Hin + sy) * p.Win + sx) * p.C1 + ci]
+                                     : p.x2[((long)(n * p.Hin + sy) * p.Win + sx) * p.C2 + (ci - p.C1)]);
+        }
+        dst[k * kSmallPix] = v;
+      }
+    }
+    __syncthreads();
+    const int m0 = (g0 + pg) * kSmallPix;
+    if (active && m0 < p.M) {
+      float acc[kSmallPix][4];
+#pragma unroll
+      for (int q = 0; q < kSmallPix; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[q][j] = bias4[j];
+      const float* pp = patch + (size_t)pg * kSmallPix * p.K;
+      for (int k = 0; k < p.K; ++k) {
+        const float4 wv = *reinterpret_cast<const float4*>(wT + k * kSmallCo + cq * 4);
+        float xq[kSmallPix];
+#pragma unroll
+        for (int q4 = 0; q4 < kSmallPix / 4; ++q4) {
+          const float4 xv4 = *reinterpret_cast<const float4*>(pp + k * kSmallPix + 4 * q4);
+          xq[4 * q4] = xv4.x; xq[4 * q4 + 1] = xv4.y; xq[4 * q4 + 2] = xv4.z; xq[4 * q4 + 3] = xv4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < kSmallPix; ++q) {
+          const float xv = xq[q];
+          acc[q][0] = fmaf(xv, wv.x, acc[q][0]); acc[q][1] = fmaf(xv, wv.y, acc[q][1]);
+          acc[q][2] = fmaf(xv, wv.z, acc[q][2]); acc[q][3] = fmaf(xv, wv.w, acc[q][3]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kSmallPix; ++q)
+        if (m0 + q < p.M) *reinterpret_cast<float4*>(p.y + (long)(m0 + q) * p.Cout + co0 + cq * 4) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    }
+  }
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int KH, int KW) {
   const long total = (long)Cout * Cin * KH * KW;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -519,11 +611,18 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
     const int cotiles = cdiv(d->Cout, kSmallCo);
     const size_t lds = ((size_t)pl.K * kSmallCo + (size_t)kSmallPG * kSmallPix * pl.K) * sizeof(float);
     static DeviceOnce once;
-    if (first_use_on_device(once))
+    if (first_use_on_device(once)) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallcin2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     int gx = cdiv(groups, kSmallPG);
     if (gx > 1024) gx = 1024;
-    MF_LAUNCH(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
+    static const int fast = [] { const char* e = getenv("MF_SMALLCIN"); return e ? atoi(e) : 1; }();   // 0: the round-5 kernel (A/B; bit-identical results)
+    if (fast && pl.K <= 255 && d->KH <= 255 && p.Cin <= 255) {
+      MF_LAUNCH(conv_smallcin2_kernel, dim3(gx, cotiles), dim3(256), lds + (size_t)pl.K * sizeof(int), s, p, groups);
+    } else {
+      MF_LAUNCH(conv_smallcin_kernel, dim3(gx, cotiles), dim3(256), lds, s, p, groups);
+    }
     return check_launch("conv_smallcin");
   }
   if (!pl.igemm && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->upsample == 0 && !p.in_nchw && d->C2 == 0 && d->Cout <= 8 &&

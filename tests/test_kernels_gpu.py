@@ -240,6 +240,46 @@ def test_conv_smallcin_two_source(dev):
     assert relerr(K.nhwc_to_nchw(y), want) < 2e-6
 
 
+def test_conv_smallcin_round6_kernel_is_bit_identical_to_the_round5_one(dev, tmp_path):
+    """conv_smallcin2_kernel (division-free patch fill, [k][pixel] patch) computes the same fma chain per output as conv_smallcin_kernel: the edge
+    convolutions of the published models (UNet in_conv 8 -> 256 NCHW in, VAE inc 3 -> 64, VAE inc_dec 8 -> 512, the two-source self-conditioning form,
+    a stride-2 case and a ragged last pixel group) give the SAME BITS from a process running the round-5 kernel (MF_SMALLCIN=0: read once per process)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    script = tmp_path / "smallcin.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {str(root)!r})
+import torch
+from medfusion_amd import kernels as K, lib as L
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1234)
+outs = []
+for n, h, w, c1, c2, co, k, st, nchw in [(16, 32, 32, 8, 0, 256, 3, 1, True), (2, 32, 32, 8, 0, 512, 3, 1, True), (2, 64, 64, 3, 0, 64, 3, 1, True),
+                                         (2, 6, 6, 8, 8, 64, 3, 1, False), (3, 9, 7, 8, 0, 64, 3, 2, False), (1, 5, 5, 4, 0, 128, 1, 1, False)]:
+    x = torch.randn((n, c1, h, w) if nchw else (n, h, w, c1), generator=g).to(dev)
+    x2 = torch.randn((n, h, w, c2), generator=g).to(dev) if c2 else None
+    wt = (torch.randn((co, c1 + c2, k, k), generator=g) * 0.2).to(dev)
+    b = torch.randn((co,), generator=g).to(dev)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, k, st, 1 if k == 3 else 0, 0, in_layout=L.LAYOUT_NCHW if nchw else L.LAYOUT_NHWC)
+    outs.append(K.conv2d(x, K.pack_conv_weight(wt), b, d, x2=x2).cpu())
+torch.save(outs, sys.argv[1])
+""")
+    res = {}
+    for mode in ("0", "1"):
+        out = tmp_path / f"y{mode}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, MF_SMALLCIN=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = torch.load(out)
+    assert len(res["0"]) == 6
+    for a, b in zip(res["0"], res["1"]):
+        assert a.shape == b.shape and torch.equal(a, b)
+        assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
+
+
 def test_conv_rejects_bad_descriptor(dev):
     from medfusion_amd import kernels as K
     x = torch.zeros((1, 4, 4, 32), device=dev)
