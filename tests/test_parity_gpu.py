@@ -800,7 +800,9 @@ def test_bulk_tail_chunk_of_69_rows_vs_oracle(dev, conv_precision):
     print(f"[measured] B = 69 (bulk tail chunk), rows {rows}: x0 per-sample rel-err every 3 iterations + final latents: " + " ".join(f"{e:.1e}" for e in errs) +
           f" | images {e_img:.1e} (RMS-relative {e_rms:.1e}) | Winograd form at 16 x 16: {K.wino_preferred(d16)}, at 8 x 8: {K.wino_preferred(d8)} "
           f"| direct plan of 512 -> 512 @16^2: {K.conv_plan(d16)}")
-    assert K.wino_preferred(d16) and not K.wino_ok(d8)
+    import os
+    if os.environ.get("MF_WINO_RULE", "1") != "0":      # (the A/B switch restores the round-5 exact-shape table, which has no B = 69 row)
+        assert K.wino_preferred(d16) and not K.wino_ok(d8)
     assert max(errs) < TOL and e_img < TOL and e_rms < TOL
 
 
