@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MF_VERSION 240 /* 0.2.4 */
+#define MF_VERSION 250 /* 0.2.5 */
 
 enum { MF_OK = 0, MF_EINVAL = -1, MF_EUNSUPPORTED = -2, MF_ELAUNCH = -3, MF_EWORKSPACE = -4 };
 enum { MF_LAYOUT_NHWC = 0, MF_LAYOUT_NCHW = 1 };
@@ -237,6 +237,19 @@ size_t mf_wino_workspace_bytes(const MfConvDesc* d);
 int mf_wino_sync_words(const MfConvDesc* d);
 int mf_wino_gn_parts(const MfConvDesc* d, int G);
 int mf_wino_plan_query(const MfConvDesc* d, int32_t* tile_id, int32_t* splitk);
+/* --- the Winograd form on the EXACT arithmetics (ABI 250): MF_CONV_FP32_SPLIT3_W3 and MF_CONV_FP32 take plain fp32 operands, so the three pieces are
+ * separate calls on fp32 tensors (same reference call sites as above: conv_blocks.py:185-191,236-240,360-363 via unet2.py:250-264):
+ *   mf_wino_f32_ok(d, G): can the 3x3 `d` (precision 0 or 3, stride 1, pad 1, NHWC, H and W even, n T % 64 == 0) with the G-group GroupNorm behind it run so?
+ *   mf_wino_input_f32: x fp32 NHWC -> V = B^T d B fp32 [16][N][(H/2)(W/2)][C]
+ *   the 16 component GEMMs: mf_conv2d_f32 with the descriptor {N = 16 n, Hin = 1, Win = T, C1, C2, Cout, KH = KW = 1, stride 1, pad 0, upsample = 3, NHWC,
+ *     precision 0 | 3}: x1 / x2 = V of the two sources, w = U = G g G^T [16][Cout][Cin] from mf_wino_pack_weight_f32 (precision 3: split by
+ *     mf_split_conv_weight_bf16x3 over rows = 16 Cout), bias NULL, y = M fp32 [16][n T][Cout]; rows [k n T, (k + 1) n T) use weight slab k
+ *   mf_wino_tail_f32: M -> y = A^T M A + bias -> GroupNorm over the whole (sample, group) -> Swish (act = 1) -> + residual (fp32 NHWC or NULL) -> + emb row;
+ *     out fp32 NHWC and, if out_wino != NULL, V of the result for the next Winograd convolution.  The kernel is the tail of the fp16-pair form. */
+int mf_wino_f32_ok(const MfConvDesc* d, int G);
+int mf_wino_input_f32(const float* x, float* v, int N, int H, int W, int C, void* stream);
+int mf_wino_tail_f32(const float* m, const float* bias, const float* gamma, const float* beta, const float* residual, const float* emb, int64_t emb_stride,
+                     float* out, float* out_wino, int N, int H, int W, int C, int G, int act, float eps, void* stream);
 int mf_conv2d_wino_f16x2(const void* v1s, const void* v2s, const void* us, const float* bias, float* y, const float* v1_bound, const float* v2_bound,
                          float u_bound, void* workspace, size_t workspace_bytes, uint32_t* sync, double* gn_partial, int G, const MfConvDesc* d,
                          void* stream);

@@ -80,6 +80,18 @@ class _Packed:
             self._wu = K.split_weight_f16x2(K.wino_pack_weight(self._raw))
         return self._wu
 
+    def get_wino_f32(self, weight: torch.Tensor, split3: bool):
+        """U = G g G^T [16, Cout, 1, 1, Cin] for the Winograd form on the exact arithmetics: plain fp32 (MF_CONV_FP32) or the bf16 triplets of
+        MF_CONV_FP32_SPLIT3_W3 (rows = 16 Cout); derived once per weight version"""
+        self.get(weight)
+        if getattr(self, "_wuf_key", None) != self._key:
+            self._wuf, self._wu3, self._wuf_key = K.wino_pack_weight(self._raw), None, self._key
+        if not split3:
+            return self._wuf
+        if self._wu3 is None:
+            self._wu3 = K.split_conv_weight(self._wuf)
+        return self._wu3
+
     def get_f16x2(self, weight: torch.Tensor) -> torch.Tensor:
         """the same weights as fp16 pairs (MF_CONV_FP32_F16X2), derived once from the fp32 packing"""
         wp = self.get(weight)
@@ -141,6 +153,10 @@ CONV_PRECISION = int(os.environ.get("MEDFUSION_CONV_PRECISION", "5"))
 WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
 
 
+# the same form on the EXACT arithmetics (CONV_PRECISION 1 = bf16 triplets; round 6, VERDICT r05 Next #9): fp32 transforms, the 16 component GEMMs on the exact
+# arithmetic's own kernel, the same tail kernel with fp32 outputs.  0 never (the direct form: what `other_conv_arithmetic` reported until round 5), 1 (default) on
+# the shapes the fp16-pair rule admits, 2 wherever the library can.  CONV_PRECISION 0 (the bit-for-bit fp32 MFMA chain) always stays on the direct form.
+WINOGRAD_F32 = int(os.environ.get("MEDFUSION_WINOGRAD_F32", "1"))
 WINO_TAIL = os.environ.get("MEDFUSION_WINOGRAD_TAIL", "1") != "0"   # the GroupNorm / Swish / residual / embedding tail in the launch behind the GEMM (A/B switch; 0: three launches)
 WINO_GROUP = os.environ.get("MEDFUSION_WINOGRAD_GROUP", "1") != "0"  # conv_res in the grid of its ResBlock's component GEMM (A/B switch; 0: its own launch)
 WINO_SHAPES = {}   # tuning hook (scripts/wino_sweep.py / wino_ab.py): (N, H, W, Cin, Cout) -> (tile, split-K) of the component GEMM (0: planner); empty in the product
@@ -272,6 +288,35 @@ class Conv(nn.Module):
                                    emb=emb, emb_stride=emb_stride, x2=x2, bconst=bconst, out_fp32=out_fp32, want_wino=want, pinned=pinned, guest=guest)
         if not want:
             y._mf_wino_site = (self._wino_sites, key)
+        return y
+
+    def forward_wino_gn_apply_f32(self, x: Act, norm, act: int, residual, emb, emb_stride):
+        """conv -> GroupNorm -> Swish -> + residual -> + emb on the Winograd form of the exact bf16-triplet arithmetic (kernels.conv2d_wino_gn_apply_f32), or
+        None when this convolution is not on that path for this shape.  Like the fp16-pair form, the output carries V for the next Winograd
+        convolution once one has asked for it (the site flag is learnt on the eager first iteration)."""
+        x1, x2 = _split(x)
+        n, h, w, c1 = x1.shape
+        c2 = 0 if x2 is None else x2.shape[-1]
+        G = norm.num_groups
+        key = ("wino_f32", n, h, w, c1, c2, G, WINOGRAD_F32)
+        ent = self._descs.get(key)
+        if ent is None:
+            ent = False
+            if self.k == 3 and self.stride == 1 and not self.upsample and c1 + c2 == self.in_ch:
+                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=3)
+                if K.wino_f32_ok(d, G) and K.conv_is_igemm(d):
+                    rule = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=5)   # (the shape rule of mf_wino_preferred speaks of the pair arithmetic's descriptor)
+                    if WINOGRAD_F32 == 2 or K.wino_preferred(rule):
+                        ent = d
+            self._descs[key] = ent
+        if ent is False:
+            return None
+        K._need_f32(x1, x2, residual)
+        want = self._wino_sites.get(key, False)
+        y = K.conv2d_wino_gn_apply_f32(x1, self._packed.get_wino_f32(self.weight, True), self.bias, ent, norm.weight, norm.bias, G, norm.eps, act=act,
+                                       residual=residual, emb=emb, emb_stride=emb_stride, x2=x2, want_wino=want)
+        if not want:
+            y._mf_wino_site_f32 = (self._wino_sites, key)
         return y
 
     def forward_gn_apply(self, x: Act, norm, act: int, residual, emb, emb_stride, out_fp32, bconst):
@@ -430,6 +475,10 @@ class BasicBlock(nn.Module):
                     return y
             if wino_guest is not None:
                 raise RuntimeError("BasicBlock: a guest convolution was planned for a Winograd launch that did not happen")
+            if CONV_PRECISION == 1 and WINOGRAD_F32 and in_layout == L.LAYOUT_NHWC and not isinstance(residual, (tuple, list)):
+                y = self.conv.forward_wino_gn_apply_f32(x, self.norm, int(self.has_act), residual, emb, emb_stride)
+                if y is not None:
+                    return y
             if f16x2_mode() and in_layout == L.LAYOUT_NHWC and not K.Rendezvous.disabled:
                 # one launch for conv + GroupNorm + Swish + residual + embedding where the plan allows it (conv_f16x2.h: FuseP)
                 nm = self.norm

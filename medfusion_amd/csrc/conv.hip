@@ -388,6 +388,9 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
   if (d->upsample == 2) {
     MF_REQUIRE(pl->igemm && hw_src % 64 == 0, MF_EUNSUPPORTED, "conv: sub-pixel form needs the implicit-GEMM path and Hin*Win %% 64 == 0 (use upsample = 1)");
   }
+  if (d->upsample == 3) {   // the component GEMMs of a Winograd convolution (conv_plan.h): implicit-GEMM path only, a tile inside one component
+    MF_REQUIRE(pl->igemm && ((long)(d->N / 16) * hw_src) % 64 == 0, MF_EUNSUPPORTED, "conv: the component GEMM needs the implicit-GEMM path and rows per component %% 64 == 0");
+  }
   if (!pl->igemm) return MF_OK;
   int nk = taps * (Cin / 32);
   if (d->tile_hint > 0) {
@@ -428,6 +431,15 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
       id = c64 ? 24 : 4;                   // 64x64 (BK = 64 when the channels allow): short-K 1x1 residual convs, stride-2 convs and
     }                                      // other < 6 GFLOP problems are launch-cost-bound: more, smaller workgroups and less split-K
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
+  }
+  if (d->upsample == 3 && ((long)(d->N / 16) * hw_src) % pl->cfg.BM) {
+    // the chosen tile straddles two components: the largest built tile of the same arithmetic whose rows divide a component
+    const long rows = (long)(d->N / 16) * hw_src;
+    const TileCfg* alt = nullptr;
+    for (const auto& k : kCfgs)
+      if (k.BK == 32 && k.id != 5 && k.id != 6 && rows % k.BM == 0 && d->Cout % k.BN == 0 && (alt == nullptr || k.BM * k.BN > alt->BM * alt->BN)) alt = &k;
+    MF_REQUIRE(alt != nullptr && d->tile_hint <= 0, MF_EUNSUPPORTED, "conv: no tile whose rows divide a component of this GEMM");
+    pl->cfg = *alt;
   }
   nk = taps * (Cin / pl->cfg.BK);
   MF_REQUIRE(d->upsample != 2 || hw_src % pl->cfg.BM == 0, MF_EINVAL, "conv: sub-pixel form needs Hin*Win %% tile rows == 0");
@@ -594,6 +606,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.cchunks = pl.igemm ? p.Cin / pl.cfg.BK : 0; p.nk = p.KH * p.KW * p.cchunks; p.nk_per_split = pl.nk_per_split; p.splitk = pl.splitk;
   p.tiles_m = 0; p.tiles_n = 0; p.slab = (long)pl.M * d->Cout;
   p.bytes1 = p.bytes2 = p.bytesw = 0;
+  p.wphase_rows = d->upsample == 3 ? (d->N / 16) * d->Hin * d->Win : 0;   // component GEMMs of a Winograd convolution: weight slab per row block
   p.gn_partial = gn_partial; p.gn_groups = G; p.gn_cpg = G > 0 ? d->Cout / G : 1;
   p.gn_parts = (gn_partial && pl.igemm && pl.splitk == 1) ? (pl.Hout * pl.Wout) / pl.cfg.BM : 0;
   if (pl.igemm && pl.splitk > 1) p.gn_partial = nullptr;  // the reducer, not the conv kernel, emits them
@@ -652,7 +665,7 @@ static int conv2d_impl(const float* x1, const float* x2, const float* w, const f
   p.tiles_m = cdiv(pl.M, pl.cfg.BM);
   p.tiles_n = d->Cout / pl.cfg.BN;
   {
-    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = (d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : d->precision == MF_CONV_BF16 ? 2.0 : 4.0) * d->Cout * pl.K * (p.subpix ? 4 : 1);
+    const double b1 = 4.0 * d->N * d->Hin * d->Win * d->C1, b2 = 4.0 * d->N * d->Hin * d->Win * d->C2, bw = (d->precision == MF_CONV_FP32_SPLIT3_W3 ? 6.0 : d->precision == MF_CONV_BF16 ? 2.0 : 4.0) * d->Cout * pl.K * (p.subpix ? 4 : d->upsample == 3 ? 16 : 1);
     MF_REQUIRE(b1 < 4294967040.0 && b2 < 4294967040.0 && bw < 4294967040.0, MF_EUNSUPPORTED,
                "conv: a source tensor exceeds the 4 GiB buffer-descriptor range (shard the batch)");
     p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;

@@ -33,6 +33,8 @@ struct ConvP {
   double* gn_partial;               // optional fused GroupNorm statistics: [N][gn_parts][G][2] = {sum, sumsq}
   int gn_groups, gn_parts, gn_cpg;
   int fastg;                        // fast gather usable: no fused nearest-x2 gather, < 2^24 source pixels, < 2^22 channels per source
+  int wphase_rows;                  // > 0: rows [k wphase_rows, (k + 1) wphase_rows) of the GEMM use weight slab k (component GEMMs of the Winograd form on the
+                                    // exact arithmetics, round 6: MfConvDesc.upsample == 3; host: wphase_rows % BM == 0)
 };
 
 // bijective XCD-aware remap: block b runs on XCD b%8; give each XCD a contiguous range of logical ids
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_kernel(const ConvP 
   }
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.bytesw, 0x00020000);
   // sub-pixel form: the tile lies inside one phase (host guarantees hw_src % BM == 0); each phase has its own [Cout][2][2][Cin] weights
-  const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : 0;
+  const int phase_t = p.subpix ? ((m0 % p.HWout) / p.hw_src) : (p.wphase_rows ? m0 / p.wphase_rows : 0);
   const unsigned wboff = (unsigned)((phase_t * p.Cout + n0 + srow) * p.K + skoff) * 4u;
   const int wrow = tid >> 2, wo = tid & 3;
   const unsigned wsoff = (unsigned)((phase_t * p.Cout + n0 + wrow) * p.K) * (2u * NP) + (unsigned)wo * (16u * NP);  // 2 NP bytes per weight

@@ -22,8 +22,12 @@ inline int fill_geometry(const MfConvDesc* d, Plan* pl) {
   MF_REQUIRE(d->N > 0 && d->Hin > 0 && d->Win > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, MF_EINVAL, "conv: bad dims");
   MF_REQUIRE((d->KH == 1 && d->KW == 1) || (d->KH == 3 && d->KW == 3), MF_EUNSUPPORTED, "conv: kernel %dx%d unsupported", d->KH, d->KW);
   MF_REQUIRE(d->stride == 1 || d->stride == 2, MF_EUNSUPPORTED, "conv: stride %d unsupported", d->stride);
-  // (upsample == 3 is INTERNAL: the component GEMMs of the Winograd form, built by mf_conv2d_wino_f16x2 itself -- conv_f16x2.hip)
-  MF_REQUIRE(d->upsample >= 0 && (d->upsample <= 2 || (d->upsample == 3 && d->precision == MF_CONV_FP32_F16X2 && d->KH == 1 && d->N % 16 == 0)), MF_EINVAL,
+  // upsample == 3: the 16 component GEMMs of a Winograd convolution -- N = 16 n pseudo-samples of Hin x Win = 1 x T tile rows, 1x1, NHWC, weights = 16
+  // slabs [16][Cout][Cin], rows [k n T, (k + 1) n T) use slab k.  On the fp16-pair arithmetic it is built by mf_conv2d_wino_f16x2 itself (conv_f16x2.hip);
+  // on the exact arithmetics (MF_CONV_FP32, MF_CONV_FP32_SPLIT3_W3) a caller passes it to mf_conv2d_f32 directly (ABI 250: mf_wino_input_f32 / mf_wino_tail_f32)
+  MF_REQUIRE(d->upsample >= 0 && (d->upsample <= 2 || (d->upsample == 3 && (d->precision == MF_CONV_FP32_F16X2 || d->precision == MF_CONV_FP32 ||
+                                                                              d->precision == MF_CONV_FP32_SPLIT3_W3) &&
+                                                           d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->N % 16 == 0)), MF_EINVAL,
              "conv: upsample flag");
   MF_REQUIRE(d->precision >= 0 && d->precision <= MF_CONV_F16, MF_EINVAL, "conv: precision flag %d", d->precision);
   MF_REQUIRE(d->upsample != 2 || (d->KH == 3 && d->stride == 1 && d->pad == 1), MF_EINVAL, "conv: the sub-pixel form is nearest-x2 + 3x3 stride 1 pad 1");

@@ -21,6 +21,7 @@
 
 namespace mfw {
 using namespace mf;
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
 
 // one thread per (cout, cin): reads the 9 taps of OIHW, writes the 16 components of [16][Cout][Cin]
 __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ u, long n) {
@@ -108,6 +109,35 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const void* __restrict_
 #pragma unroll
       for (int k = 0; k < 16; ++k) vbound[k * N + n] = vb;
     }
+  }
+}
+
+// The same transform on fp32 tensors (round 6: the Winograd form on the EXACT arithmetics -- MF_CONV_FP32_SPLIT3_W3 / MF_CONV_FP32 -- whose operands
+// are plain fp32): x fp32 NHWC [N][H][W][C] -> V = B^T d B fp32 [16][N][T][C].  One thread per (sample, tile, 4 channels).
+__global__ __launch_bounds__(256) void wino_input_f32_kernel(const float* __restrict__ x, float* __restrict__ v, int N, int H, int W, int C) {
+  const int C4 = C >> 2, TW = W >> 1, T = (H >> 1) * TW;
+  const long total = (long)N * T * C4, stride = (long)gridDim.x * 256;
+  const long plane = (long)N * T * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c4 = (int)(i % C4);
+    const long r = i / C4;
+    const int tile = (int)(r % T), n = (int)(r / T);
+    const int ty = tile / TW, tx = tile - ty * TW;
+    float d[4][16];
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const int y = 2 * ty - 1 + py, xx = 2 * tx - 1 + px;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) q = *reinterpret_cast<const float4*>(x + (((long)n * H + y) * W + xx) * C + c4 * 4);
+        d[0][4 * py + px] = q.x; d[1][4 * py + px] = q.y; d[2][4 * py + px] = q.z; d[3][4 * py + px] = q.w;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wino_bt_d_b(d[k]);
+    const long e0 = ((long)n * T + tile) * C + c4 * 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) __builtin_nontemporal_store(wf32x4{d[0][k], d[1][k], d[2][k], d[3][k]}, reinterpret_cast<wf32x4*>(v + (long)k * plane + e0));
   }
 }
 
@@ -212,6 +242,7 @@ struct WinoTailP {
   int N, H, W, C, G, act;
   float eps, bconst;
   int v_nt;                     // 1: the transform-domain output goes out with non-temporal stores (MF_WINO_VSTORE, A/B)
+  int v_f32;                    // 1: fp32 mode (the exact arithmetics, round 6): out_wino is fp32 [16][N][T][C], no pair rounding, no scales; out_pairs null
   int xcd_map;                  // 1: consecutive groups of a sample run on ONE XCD (round 6, MF_WINO_TAIL_MAP): at 16 channels per group two groups share
                                 // every 128-byte line of M / V / the pair outputs -- with the plain (g, n) grid they sat on different XCDs (different L2s)
 };
@@ -371,7 +402,8 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
     if (p.emb) { e[0] += em.x; e[1] += em.y; e[2] += em.z; e[3] += em.w; }                                            \
     if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + eo) = make_float4(e[0], e[1], e[2], e[3]);                  \
     if (p.out_pairs) store_split4<false>(p.out_pairs, eo, e[0], e[1], e[2], e[3], osc);   /* (the bound is derived: no clamp, split_f16.h) */ \
-    if (keep) *reinterpret_cast<float4*>(yp) = make_float4(wino_pair_round(e[0] * osc), wino_pair_round(e[1] * osc), wino_pair_round(e[2] * osc), wino_pair_round(e[3] * osc)); \
+    if (keep) *reinterpret_cast<float4*>(yp) = p.v_f32 ? make_float4(e[0], e[1], e[2], e[3])                                                                     \
+                                                       : make_float4(wino_pair_round(e[0] * osc), wino_pair_round(e[1] * osc), wino_pair_round(e[2] * osc), wino_pair_round(e[3] * osc)); \
   }
 #pragma unroll
   for (int j = 0; j < RJ; ++j) {
@@ -400,7 +432,11 @@ __global__ __launch_bounds__(256) void wino_tail_kernel(const WinoTailP p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) wino_bt_d_b(d[k]);
     const long e0 = ((long)n * T + t) * C + c0 + c4 * 4;
-    if (p.v_nt) {
+    if (p.v_f32) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        __builtin_nontemporal_store(wf32x4{d[0][k], d[1][k], d[2][k], d[3][k]}, reinterpret_cast<wf32x4*>(reinterpret_cast<float*>(p.out_wino) + (long)k * plane + e0));
+    } else if (p.v_nt) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) store_split4<true, true>(p.out_wino, (long)k * plane + e0, d[0][k], d[1][k], d[2][k], d[3][k], f);
     } else {

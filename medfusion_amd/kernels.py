@@ -290,6 +290,8 @@ def drop_split(t: Optional[torch.Tensor]) -> None:
             t._mf_slots = None
         if getattr(t, "_mf_wino", None) is not None:
             t._mf_wino = t._mf_wino_bound = None
+        if getattr(t, "_mf_wino_f32", None) is not None:
+            t._mf_wino_f32 = None
 
 
 def maxabs_rows(x: torch.Tensor) -> torch.Tensor:
@@ -675,6 +677,57 @@ def conv2d_wino_gn_apply(x1: torch.Tensor, u_split, bias: Optional[torch.Tensor]
     _audit(out, "Winograd tail (derived: bconst + residual + embedding)")
     if not out_fp32:
         out._mf_pairs_only = True
+    return out
+
+
+# ----------------------------------------------------------------------------- the Winograd form on the EXACT arithmetics (round 6, ABI 250)
+def wino_f32_ok(d: L.MfConvDesc, G: int) -> bool:
+    """can the 3x3 `d` (precision 0 = fp32 MFMA or 3 = exact bf16 triplets) with the G-group GroupNorm behind it run as fp32 transforms + component GEMMs
+    on the exact arithmetic's own kernel + the tail?  (mf_wino_f32_ok)"""
+    return bool(L.load().mf_wino_f32_ok(C.byref(d), G))
+
+
+def wino_input_f32(x: torch.Tensor) -> torch.Tensor:
+    """V = B^T d B of the fp32 NHWC activation x as fp32 [16, N, T, C], cached on x; a tensor whose producer could have written V itself
+    (conv2d_wino_gn_apply_f32: `_mf_wino_site_f32`) tells it so here, like wino_input does for the fp16-pair form"""
+    v = _fresh(x, "_mf_wino_f32")
+    if v is None:
+        _need_f32(x)
+        site = getattr(x, "_mf_wino_site_f32", None)
+        if site is not None:
+            site[0][site[1]] = True
+        n, h, w, c = x.shape
+        v = torch.empty((16, n, (h // 2) * (w // 2), c), dtype=torch.float32, device=x.device)
+        L.check(L.load().mf_wino_input_f32(x.data_ptr(), v.data_ptr(), n, h, w, c, stream()), "mf_wino_input_f32")
+        x._mf_wino_f32 = v
+        _stamp(x)
+    return v
+
+
+def conv2d_wino_gn_apply_f32(x1: torch.Tensor, u_packed: torch.Tensor, bias: Optional[torch.Tensor], d: L.MfConvDesc, gamma, beta, G: int, eps: float,
+                             act: int = 1, residual: Optional[torch.Tensor] = None, emb: Optional[torch.Tensor] = None, emb_stride: int = 0,
+                             x2: Optional[torch.Tensor] = None, want_wino: bool = False) -> torch.Tensor:
+    """conv3x3 -> GroupNorm -> Swish -> + residual -> + emb on the Winograd form of an EXACT arithmetic (d.precision 0 or 3): the 16 component GEMMs run on
+    that arithmetic's own implicit-GEMM kernel (mf_conv2d_f32 on the upsample = 3 descriptor; u_packed = U = G g G^T [16, Cout, 1, 1, Cin], pre-split for
+    precision 3), the transforms and the tail are fp32.  Returns y fp32 NHWC; want_wino: it also carries V of y for the next Winograd convolution."""
+    _gpu(x1, x2, u_packed, bias, gamma, beta, residual, emb)
+    lib = L.load()
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    co, t = d.Cout, (h // 2) * (w // 2)
+    v1 = wino_input_f32(x1)
+    v2 = wino_input_f32(x2) if x2 is not None else None
+    g = make_conv_desc(16 * n, 1, t, c1, c2, co, 1, 1, 0, 3, precision=d.precision)
+    m = conv2d(v1.view(16 * n, 1, t, c1), u_packed, None, g, x2=None if v2 is None else v2.view(16 * n, 1, t, c2))
+    if residual is not None:
+        _need_f32(residual)
+    out = torch.empty((n, h, w, co), dtype=torch.float32, device=x1.device)
+    ov = torch.empty((16, n, t, co), dtype=torch.float32, device=x1.device) if want_wino else None
+    L.check(lib.mf_wino_tail_f32(m.data_ptr(), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(residual), _ptr(emb), emb_stride, out.data_ptr(), _ptr(ov),
+                                 n, h, w, co, G, act, eps, stream()), "mf_wino_tail_f32")
+    if want_wino:
+        out._mf_wino_f32 = ov
+        _stamp(out)
     return out
 
 

@@ -93,6 +93,9 @@ _SIGS = {
     "mf_wino_sync_words": (_I, [C.POINTER(MfConvDesc)]),
     "mf_wino_gn_parts": (_I, [C.POINTER(MfConvDesc), _I]),
     "mf_wino_plan_query": (_I, [C.POINTER(MfConvDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mf_wino_f32_ok": (_I, [C.POINTER(MfConvDesc), _I]),
+    "mf_wino_input_f32": (_I, [c_fp, c_fp, _I, _I, _I, _I, c_fp]),
+    "mf_wino_tail_f32": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _I64, c_fp, c_fp, _I, _I, _I, _I, _I, _I, _F, c_fp]),
     "mf_conv2d_wino_f16x2": (_I, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, _F, c_fp, _SZ, c_fp, c_fp, _I, C.POINTER(MfConvDesc), c_fp]),
     "mf_wino_tail_ok": (_I, [C.POINTER(MfConvDesc), _I]),
     "mf_wino_group_ok": (_I, [C.POINTER(MfConvDesc), C.POINTER(MfConvDesc)]),

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(L.exported_symbols()), declared ^ set(L.exported_symbols())
-    assert lib.mf_version() == 240
+    assert lib.mf_version() == 250
     assert lib.mf_prof_family_name(0) == b"conv_igemm"
 
 
@@ -251,7 +251,7 @@ int main(void) {
     ver, rc, ok, tile, sk = map(int, out[0].split())
     from medfusion_amd import kernels as K
     want = K.conv_plan(K.make_conv_desc(16, 32, 32, 256, 0, 256, 3, 1, 1, 0, precision=5))
-    assert (ver, rc, ok) == (240, 0, 1) and (tile, sk) == want
+    assert (ver, rc, ok) == (250, 0, 1) and (tile, sk) == want
     assert out[1].startswith("0|") and "unsupported" in out[1]
 
 

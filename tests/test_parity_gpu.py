@@ -45,16 +45,18 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[(5, 1), (5, 2), (1, 1), (0, 1)], ids=["f16x2", "f16x2_winograd_everywhere", "split3", "fp32mfma"], autouse=True)
+@pytest.fixture(params=[(5, 1, 1), (5, 2, 1), (1, 1, 0), (1, 1, 2), (0, 1, 1)], ids=["f16x2", "f16x2_winograd_everywhere", "split3", "split3_winograd_everywhere", "fp32mfma"],
+                autouse=True)
 def conv_precision(request):
     """every parity test runs on all three fp32-class conv arithmetics (MF_CONV_FP32_F16X2, MF_CONV_FP32_SPLIT3_W3, MF_CONV_FP32), same tolerances;
-    the default arithmetic twice: as shipped (the Winograd form on the shapes of csrc/wino_plan_table.inc) and with that form wherever the
-    library can run it (blocks.WINOGRAD = 2)"""
+    the default arithmetic twice: as shipped (the Winograd form where mf_wino_preferred says so) and with that form wherever the library can run it
+    (blocks.WINOGRAD = 2); the exact bf16-triplet arithmetic twice as well: on the direct form (WINOGRAD_F32 = 0) and with the round-6 Winograd form of
+    the exact arithmetics wherever the library can run it (WINOGRAD_F32 = 2); the fp32 MFMA chain always runs direct"""
     from medfusion_amd import blocks as BLK
-    old = BLK.CONV_PRECISION, BLK.WINOGRAD
-    BLK.CONV_PRECISION, BLK.WINOGRAD = request.param
+    old = BLK.CONV_PRECISION, BLK.WINOGRAD, BLK.WINOGRAD_F32
+    BLK.CONV_PRECISION, BLK.WINOGRAD, BLK.WINOGRAD_F32 = request.param
     yield request.param[0]
-    BLK.CONV_PRECISION, BLK.WINOGRAD = old
+    BLK.CONV_PRECISION, BLK.WINOGRAD, BLK.WINOGRAD_F32 = old
 
 
 def nhwc(x, dev):

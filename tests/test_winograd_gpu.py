@@ -326,3 +326,82 @@ def test_conv_res_in_the_grid_of_the_component_gemm(dev, shape):
         BLK.WINOGRAD, BLK.WINO_GROUP = old
     assert torch.equal(outs[True], outs[False]), shape
     assert counts[True] == counts[False] - 1 == 2, counts     # GEMM (+ conv_res in its grid) and the tail
+
+
+F32_TAIL_CASES = [
+    # (N, H, W, C1, C2, Cout, G, residual, emb, affine, act, precision)
+    (16, 8, 8, 1024, 0, 1024, 32, True, True, True, 1, 3),      # published 8 x 8 level, exact bf16 triplets
+    (16, 8, 8, 1024, 512, 512, 32, True, True, True, 1, 3),     # two-source out block
+    (16, 16, 16, 512, 0, 512, 32, True, False, True, 1, 3),     # published 16 x 16 level
+    (4, 16, 16, 64, 0, 128, 8, False, False, False, 0, 3),      # no affine, no act, no residual
+    (2, 32, 32, 64, 0, 256, 32, True, True, True, 1, 3),
+    (16, 8, 8, 512, 0, 1024, 32, True, True, True, 1, 0),       # the same pieces on the fp32 MFMA kernel
+]
+
+
+@pytest.mark.parametrize("case", F32_TAIL_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_wino_gn_apply_on_the_exact_arithmetics(dev, case):
+    """Round 6 (ABI 250): the Winograd form on MF_CONV_FP32_SPLIT3_W3 / MF_CONV_FP32 -- fp32 input transform, the 16 component GEMMs on the exact
+    arithmetic's own implicit-GEMM kernel (upsample = 3 descriptor), the tail kernel of the fp16-pair form in its fp32 mode -- against (a) the DIRECT
+    convolution of the same arithmetic + the GroupNorm apply pass and (b) the chain in fp64; its transform-domain output equals the stand-alone fp32
+    transform of its own output bit for bit."""
+    from medfusion_amd import kernels as K, lib as L
+    n, h, w, c1, c2, co, G, has_res, has_emb, affine, act, prec = case
+    cin = c1 + c2
+    x = _rand(f"fx{case}", (n, c1, h, w))
+    x2 = _rand(f"fy{case}", (n, c2, h, w)) if c2 else None
+    wt = _rand(f"fw{case}", (co, cin, 3, 3), 1.0 / np.sqrt(cin * 9))
+    b = _rand(f"fb{case}", (co,), 0.1)
+    gamma = (1.0 + 0.3 * _rand(f"fg{case}", (co,))) if affine else None
+    beta = 0.2 * _rand(f"fbe{case}", (co,)) if affine else None
+    res = _rand(f"fr{case}", (n, co, h, w), 2.0) if has_res else None
+    emb = _rand(f"fe{case}", (n, co), 0.5) if has_emb else None
+    xd = K.nchw_to_nhwc(x.to(dev))
+    x2d = K.nchw_to_nhwc(x2.to(dev)) if c2 else None
+    resd = K.nchw_to_nhwc(res.to(dev)) if has_res else None
+    embd = emb.to(dev) if has_emb else None
+    gd, bd = (gamma.to(dev), beta.to(dev)) if affine else (None, None)
+    d = K.make_conv_desc(n, h, w, c1, c2, co, 3, 1, 1, 0, precision=prec)
+    assert K.wino_f32_ok(d, G), case
+    u = K.wino_pack_weight(wt.to(dev))
+    u = K.split_conv_weight(u) if prec == 3 else u
+    got = K.conv2d_wino_gn_apply_f32(xd, u, b.to(dev), d, gd, bd, G, 1e-5, act=act, residual=resd, emb=embd, emb_stride=embd.stride(0) if has_emb else 0, x2=x2d,
+                                     want_wino=True)
+    # (a) the direct form of the same arithmetic
+    wp = K.pack_conv_weight(wt.to(dev))
+    wp = K.split_conv_weight(wp) if prec == 3 else wp
+    y = K.conv2d(xd, wp, b.to(dev), d, x2=x2d)
+    ref = K.gn_apply(y, K.gn_stats(y, G, 1e-5), gd, bd, G, act, resd, embd, embd.stride(0) if has_emb else 0)
+    e_direct = relerr(got, ref)
+    # (b) fp64
+    xin = x if x2 is None else torch.cat([x, x2], 1)
+    y64 = F.conv2d(xin.double(), wt.double(), b.double(), padding=1)
+    t64 = F.group_norm(y64, G, gamma.double() if affine else None, beta.double() if affine else None, 1e-5)
+    if act:
+        t64 = t64 * torch.sigmoid(t64)
+    if has_res:
+        t64 = t64 + res.double()
+    if has_emb:
+        t64 = t64 + emb.double()[:, :, None, None]
+    e64 = relerr(K.nhwc_to_nchw(got), t64)
+    e64d = relerr(K.nhwc_to_nchw(ref), t64)
+    print(f"[measured] winograd on the exact arithmetic {case}: vs fp64 chain {e64:.2e} (direct form of the same arithmetic: {e64d:.2e}); vs that direct form {e_direct:.2e}")
+    assert e64 < 5e-6 and e_direct < 5e-6, (case, e64, e_direct)
+    v = got._mf_wino_f32
+    got2 = got.clone()
+    assert torch.equal(K.wino_input_f32(got2), v), case
+    # V against an fp64 transform of the output
+    T = (h // 2) * (w // 2)
+    g64 = F.pad(K.nhwc_to_nchw(got).cpu().double(), (1, 1, 1, 1))
+    patches = g64.unfold(2, 4, 2).unfold(3, 4, 2)                       # [n, c, h/2, w/2, 4, 4]
+    v64 = torch.einsum("ij,nchwjk,lk->ilnhwc", BT, patches, BT).reshape(16, n, T, co)
+    assert relerr(v, v64) < 1e-6, case
+
+
+def test_wino_f32_refuses_what_it_cannot_do(dev):
+    from medfusion_amd import kernels as K
+    assert not K.wino_f32_ok(K.make_conv_desc(16, 8, 8, 1024, 0, 1024, 3, 1, 1, 0, precision=5), 32)     # the pair arithmetic has its own entry points
+    assert not K.wino_f32_ok(K.make_conv_desc(16, 8, 8, 1024, 0, 1024, 3, 2, 1, 0, precision=3), 32)     # stride 2
+    assert not K.wino_f32_ok(K.make_conv_desc(3, 8, 8, 1024, 0, 1024, 3, 1, 1, 0, precision=3), 32)      # 48 tile rows per component: no tile
+    assert not K.wino_f32_ok(K.make_conv_desc(2, 64, 64, 64, 0, 512, 3, 1, 1, 0, precision=3), 32)       # 64 x 64 x 16 channels do not fit in LDS
+    assert K.wino_f32_ok(K.make_conv_desc(16, 16, 16, 512, 0, 512, 3, 1, 1, 0, precision=3), 32)
