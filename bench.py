@@ -46,7 +46,8 @@ ARITH = {
             text="fp32 MFMA (v_mfma_f32_32x32x2_f32): bit-for-bit an fp32 fma chain"),
     1: dict(kernel="conv_igemm_kernel<..., MODE 3>", pmc_match=("conv_igemm_kernel<", ", 3, "), terms=6, peak=PEAK_MFMA16_TFLOPS, dtype="f32",
             text="fp32 operands split EXACTLY into 3 bf16 terms (24 bits), 6 product terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate; weights "
-                 "pre-split at load"),
+                 "pre-split at load.  Round 6: the 3x3 stride-1 convolutions of the 8 x 8 and 16 x 16 levels in their Winograd F(2x2,3x3) form on THIS arithmetic "
+                 "(fp32 transforms, component GEMMs on this kernel with exactly split operands; `direct_form_everywhere` = the configuration of rounds 1-5)"),
     4: dict(kernel="conv_igemm_kernel<..., MODE 5>", pmc_match=("conv_igemm_kernel<", ", 5, "), terms=1, peak=PEAK_MFMA16_TFLOPS,
             dtype="bf16 operands / f32 accumulate (opt-in, NOT the headline configuration)",
             text="REDUCED precision: conv operands rounded to bf16 (round to nearest even), one MFMA term, fp32 accumulate; everything else fp32"),
@@ -418,7 +419,22 @@ def main():
             BLK.CONV_PRECISION = a
             one_step(2000)
             dta = timed(max(1, args.steps)) / max(1, args.steps)
-            alts.append({"conv_precision": a, "arithmetic": ARITH[a]["text"], "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)})
+            ent = {"conv_precision": a, "arithmetic": ARITH[a]["text"], "value": round(n_global / dta, 4), "unit": "images/s", "ms_per_step": round(dta * 1e3, 2)}
+            if a == 1:
+                # round 6: the exact bf16-triplet arithmetic takes the Winograd F(2x2,3x3) form on the shapes mf_wino_preferred admits (fp32 transforms, the component
+                # GEMMs on its own kernel, the same tail; blocks.WINOGRAD_F32).  The direct form everywhere -- what this entry measured in rounds 1-5 -- next to it.
+                ent["winograd_form"] = {0: "none: direct form everywhere", 1: "on the shapes mf_wino_preferred admits (8 x 8 and 16 x 16 levels)", 2: "wherever the library can"}[BLK.WINOGRAD_F32]
+                if BLK.WINOGRAD_F32:
+                    wf = BLK.WINOGRAD_F32
+                    BLK.WINOGRAD_F32 = 0
+                    one_step(2100)
+                    k = max(1, min(3, args.steps))
+                    dtd = timed(k) / k
+                    BLK.WINOGRAD_F32 = wf
+                    ent["direct_form_everywhere"] = {"value": round(n_global / dtd, 4), "unit": "images/s", "ms_per_step": round(dtd * 1e3, 2), "steps": k}
+            if a == 0:
+                ent["winograd_form"] = "none: this entry is the bit-for-bit fp32 fma chain of the direct convolution, on purpose"
+            alts.append(ent)
         BLK.CONV_PRECISION = prec
     reduced = []
     if not args.no_alt_path and rank == 0 and world == 1 and args.alt_precision is None and args.conv_precision is None:
