@@ -434,6 +434,15 @@ def main():
                     ent["direct_form_everywhere"] = {"value": round(n_global / dtd, 4), "unit": "images/s", "ms_per_step": round(dtd * 1e3, 2), "steps": k}
             if a == 0:
                 ent["winograd_form"] = "none: this entry is the bit-for-bit fp32 fma chain of the direct convolution, on purpose"
+                # ... and, next to it, the same kernel running the Winograd component GEMMs (opt-in blocks.WINOGRAD_F32_MFMA: fp32 transforms, v_mfma_f32_32x32x2_f32
+                # on unsplit fp32 operands, fp32 tail -- no operand splitting anywhere; another summation than the direct chain)
+                BLK.WINOGRAD_F32_MFMA = 1
+                one_step(2200)
+                k = max(1, min(3, args.steps))
+                dtw = timed(k) / k
+                BLK.WINOGRAD_F32_MFMA = 0
+                ent["with_the_winograd_form_opt_in"] = {"value": round(n_global / dtw, 4), "unit": "images/s", "ms_per_step": round(dtw * 1e3, 2), "steps": k,
+                                                        "what": "MEDFUSION_WINOGRAD_F32_MFMA=1: 3x3 stride-1 convolutions of the 8 x 8 / 16 x 16 levels as fp32 Winograd F(2x2,3x3)"}
             alts.append(ent)
         BLK.CONV_PRECISION = prec
     reduced = []

@@ -157,6 +157,9 @@ WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
 # arithmetic's own kernel, the same tail kernel with fp32 outputs.  0 never (the direct form: what `other_conv_arithmetic` reported until round 5), 1 (default) on
 # the shapes the fp16-pair rule admits, 2 wherever the library can.  CONV_PRECISION 0 (the bit-for-bit fp32 MFMA chain) always stays on the direct form.
 WINOGRAD_F32 = int(os.environ.get("MEDFUSION_WINOGRAD_F32", "1"))
+# ... and, opt-in only, on CONV_PRECISION 0: the plain fp32 MFMA kernel runs the component GEMMs (no operand splitting anywhere: fp32 transforms, fp32 matrix
+# instructions, fp32 tail) -- bench.py times it next to the direct chain; the default for CONV_PRECISION 0 stays the bit-for-bit direct form
+WINOGRAD_F32_MFMA = int(os.environ.get("MEDFUSION_WINOGRAD_F32_MFMA", "0"))
 WINO_TAIL = os.environ.get("MEDFUSION_WINOGRAD_TAIL", "1") != "0"   # the GroupNorm / Swish / residual / embedding tail in the launch behind the GEMM (A/B switch; 0: three launches)
 WINO_GROUP = os.environ.get("MEDFUSION_WINOGRAD_GROUP", "1") != "0"  # conv_res in the grid of its ResBlock's component GEMM (A/B switch; 0: its own launch)
 WINO_SHAPES = {}   # tuning hook (scripts/wino_sweep.py / wino_ab.py): (N, H, W, Cin, Cout) -> (tile, split-K) of the component GEMM (0: planner); empty in the product
@@ -290,7 +293,7 @@ class Conv(nn.Module):
             y._mf_wino_site = (self._wino_sites, key)
         return y
 
-    def forward_wino_gn_apply_f32(self, x: Act, norm, act: int, residual, emb, emb_stride):
+    def forward_wino_gn_apply_f32(self, x: Act, norm, act: int, residual, emb, emb_stride, split3: bool = True):
         """conv -> GroupNorm -> Swish -> + residual -> + emb on the Winograd form of the exact bf16-triplet arithmetic (kernels.conv2d_wino_gn_apply_f32), or
         None when this convolution is not on that path for this shape.  Like the fp16-pair form, the output carries V for the next Winograd
         convolution once one has asked for it (the site flag is learnt on the eager first iteration)."""
@@ -298,22 +301,23 @@ class Conv(nn.Module):
         n, h, w, c1 = x1.shape
         c2 = 0 if x2 is None else x2.shape[-1]
         G = norm.num_groups
-        key = ("wino_f32", n, h, w, c1, c2, G, WINOGRAD_F32)
+        mode = WINOGRAD_F32 if split3 else WINOGRAD_F32_MFMA
+        key = ("wino_f32", n, h, w, c1, c2, G, mode, split3)
         ent = self._descs.get(key)
         if ent is None:
             ent = False
             if self.k == 3 and self.stride == 1 and not self.upsample and c1 + c2 == self.in_ch:
-                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=3)
+                d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=3 if split3 else 0)
                 if K.wino_f32_ok(d, G) and K.conv_is_igemm(d):
                     rule = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=5)   # (the shape rule of mf_wino_preferred speaks of the pair arithmetic's descriptor)
-                    if WINOGRAD_F32 == 2 or K.wino_preferred(rule):
+                    if mode == 2 or K.wino_preferred(rule):
                         ent = d
             self._descs[key] = ent
         if ent is False:
             return None
         K._need_f32(x1, x2, residual)
         want = self._wino_sites.get(key, False)
-        y = K.conv2d_wino_gn_apply_f32(x1, self._packed.get_wino_f32(self.weight, True), self.bias, ent, norm.weight, norm.bias, G, norm.eps, act=act,
+        y = K.conv2d_wino_gn_apply_f32(x1, self._packed.get_wino_f32(self.weight, split3), self.bias, ent, norm.weight, norm.bias, G, norm.eps, act=act,
                                        residual=residual, emb=emb, emb_stride=emb_stride, x2=x2, want_wino=want)
         if not want:
             y._mf_wino_site_f32 = (self._wino_sites, key)
@@ -475,8 +479,8 @@ class BasicBlock(nn.Module):
                     return y
             if wino_guest is not None:
                 raise RuntimeError("BasicBlock: a guest convolution was planned for a Winograd launch that did not happen")
-            if CONV_PRECISION == 1 and WINOGRAD_F32 and in_layout == L.LAYOUT_NHWC and not isinstance(residual, (tuple, list)):
-                y = self.conv.forward_wino_gn_apply_f32(x, self.norm, int(self.has_act), residual, emb, emb_stride)
+            if ((CONV_PRECISION == 1 and WINOGRAD_F32) or (CONV_PRECISION == 0 and WINOGRAD_F32_MFMA)) and in_layout == L.LAYOUT_NHWC and not isinstance(residual, (tuple, list)):
+                y = self.conv.forward_wino_gn_apply_f32(x, self.norm, int(self.has_act), residual, emb, emb_stride, split3=CONV_PRECISION == 1)
                 if y is not None:
                     return y
             if f16x2_mode() and in_layout == L.LAYOUT_NHWC and not K.Rendezvous.disabled:

@@ -405,6 +405,32 @@ def test_cfg1_published_golden(dev, published):
 
 
 @torch.no_grad()
+def test_fp32_mfma_with_the_winograd_form_opt_in(dev, published, conv_precision):
+    """blocks.WINOGRAD_F32_MFMA = 1 (opt-in; bench.py times it next to the bit-for-bit direct chain): the plain fp32 MFMA kernel runs the component GEMMs of the
+    8 x 8 / 16 x 16 levels -- no operand splitting anywhere.  Published UNet, B = 4 (n T = 64 tile rows per component at the 8 x 8 level), against the oracle and
+    against the direct chain of the same arithmetic."""
+    if conv_precision != 0:
+        pytest.skip("runs once")
+    from medfusion_amd import blocks as BLK
+    ora, pipe = published
+    x = S.synth_input("pub256_x4", (4, 8, 32, 32))
+    t = torch.tensor([731, 12, 400, 999])
+    c = torch.tensor([1, 0, 1, 0])
+    want, _ = ora.noise_estimator(x, t, c)
+    direct, _ = pipe.noise_estimator(x.to(dev), t.to(dev), c.to(dev))
+    BLK.WINOGRAD_F32_MFMA = 1
+    try:
+        got, _ = pipe.noise_estimator(x.to(dev), t.to(dev), c.to(dev))
+        got2, _ = pipe.noise_estimator(x.to(dev), t.to(dev), c.to(dev))      # second evaluation: the producers write V themselves now
+    finally:
+        BLK.WINOGRAD_F32_MFMA = 0
+    e, ed = relerr_rows(got, want), relerr_rows(direct, want)
+    print(f"[measured] fp32 MFMA with the Winograd form (opt-in): UNet per-sample relerr vs the oracle {e:.2e} (direct chain: {ed:.2e}); vs the direct chain {relerr_rows(got, direct):.2e}")
+    assert e < TOL and not torch.equal(got, direct)          # (it really took the other form)
+    assert torch.equal(got, got2)
+
+
+@torch.no_grad()
 def test_published_unet_and_decode_vs_oracle_256px(dev, published):
     """Full published shapes: latent (8,32,32) -> 256x256 image.  Oracle evaluated on CPU on the same inputs."""
     ora, pipe = published
