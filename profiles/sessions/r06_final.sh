@@ -1,12 +1,12 @@
 #!/bin/bash
 # round-6 final GPU session: the full GPU suite (with the [measured] lines), smoke, PMC traffic of the final tree (stamped), rocprofv3 kernel stats + idle-time
-# analysis of the bench command, the driver-style bench line.  Everything lands in gpurun_out/r06final/; the summaries are copied to profiles/ by hand.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06final
+# analysis of the bench command, the driver-style bench line.  Everything lands in gpurun_out/r06final3/; the summaries are copied to profiles/ by hand.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06final3
 mkdir -p $O/prof
 cd $R
 timeout 2700 python -m pytest tests -m gpu -q -s > $O/tests_all.txt 2>&1; tail -4 $O/tests_all.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 1500 bash scripts/pmc_bench_traffic.sh gpurun_out/r06final/pmc_traffic > $O/pmc_traffic.txt 2>&1; tail -9 $O/pmc_traffic.txt
+timeout 1500 bash scripts/pmc_bench_traffic.sh gpurun_out/r06final3/pmc_traffic > $O/pmc_traffic.txt 2>&1; tail -9 $O/pmc_traffic.txt
 rm -f $O/pmc_traffic/*_counter_collection.csv $O/pmc_traffic/*kernel_trace.csv $O/pmc_traffic/*agent_info*
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o bench --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-path --no-roofline --no-other-workloads > $O/prof_bench.json 2> $O/prof_bench.err
