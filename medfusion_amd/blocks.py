@@ -155,7 +155,7 @@ WINOGRAD = int(os.environ.get("MEDFUSION_WINOGRAD", "1"))
 
 # the same form on the EXACT arithmetics (CONV_PRECISION 1 = bf16 triplets; round 6, VERDICT r05 Next #9): fp32 transforms, the 16 component GEMMs on the exact
 # arithmetic's own kernel, the same tail kernel with fp32 outputs.  0 never (the direct form: what `other_conv_arithmetic` reported until round 5), 1 (default) on
-# the shapes the fp16-pair rule admits, 2 wherever the library can.  CONV_PRECISION 0 (the bit-for-bit fp32 MFMA chain) always stays on the direct form.
+# the shapes the fp16-pair rule admits and every shape up to 16 x 16, 2 wherever the library can.  CONV_PRECISION 0 (the bit-for-bit fp32 MFMA chain) always stays on the direct form.
 WINOGRAD_F32 = int(os.environ.get("MEDFUSION_WINOGRAD_F32", "1"))
 # ... and, opt-in only, on CONV_PRECISION 0: the plain fp32 MFMA kernel runs the component GEMMs (no operand splitting anywhere: fp32 transforms, fp32 matrix
 # instructions, fp32 tail) -- bench.py times it next to the direct chain; the default for CONV_PRECISION 0 stays the bit-for-bit direct form
@@ -310,7 +310,9 @@ class Conv(nn.Module):
                 d = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=3 if split3 else 0)
                 if K.wino_f32_ok(d, G) and K.conv_is_igemm(d):
                     rule = K.make_conv_desc(n, h, w, c1, c2, self.out_ch, 3, 1, 1, 0, precision=5)   # (the shape rule of mf_wino_preferred speaks of the pair arithmetic's descriptor)
-                    if mode == 2 or K.wino_preferred(rule):
+                    # (1: the pair arithmetic's rule, plus every shape up to 16 x 16 -- with six matrix terms per product the low-channel shapes the pair
+                    # arithmetic leaves direct gain here too: +0.95 % on the step, profiles/r06_small_ab.txt section 7; the 32 x 32 level loses: mode 2)
+                    if mode == 2 or h * w <= 256 or K.wino_preferred(rule):
                         ent = d
             self._descs[key] = ent
         if ent is False:
