@@ -432,6 +432,28 @@ int make_plan(const MfConvDesc* d, Plan* pl) {
     }                                      // other < 6 GFLOP problems are launch-cost-bound: more, smaller workgroups and less split-K
     for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
   }
+  static const int gemm_rule = [] { const char* e = getenv("MF_WINO_F32_PLAN"); return e ? atoi(e) : 1; }();   // 0: the generic rule above (A/B)
+  if (d->upsample == 3 && d->tile_hint <= 0 && gemm_rule) {
+    // the component GEMMs of a Winograd convolution (scripts/wino_f32_sweep.py on MI355X, B = 16: the generic rule above was 10 - 25 % off the best on eight of
+    // ten shapes): the LARGEST tile that still gives one workgroup per CU without split-K -- 128 x 256, then 128 x 128 --, else 128 x 128 with the K loop
+    // split in two where that loop is long enough (>= 32 chunks), else 64 x 128
+    const long rows = (long)(d->N / 16) * hw_src;
+    auto tiles_of = [&](int bm, int bn) { return rows % bm == 0 && d->Cout % bn == 0 ? (long)cdiv(pl->M, bm) * (d->Cout / bn) : 0L; };
+    int id = 0, sk = 0;
+    if (tiles_of(128, 256) >= 256) { id = 9; sk = 1; }
+    else if (tiles_of(128, 128) >= 256) { id = 8; sk = 1; }
+    else if (tiles_of(128, 128) >= 128 && Cin / 32 >= 32) { id = 8; sk = 2; }
+    else if (tiles_of(64, 128) > 0) { id = 3; sk = 1; }
+    if (id) {
+      for (const auto& k : kCfgs) if (k.id == id) pl->cfg = k;
+      if (d->splitk_hint <= 0) {
+        nk = Cin / pl->cfg.BK;
+        pl->nk_per_split = cdiv(nk, sk);
+        pl->splitk = cdiv(nk, pl->nk_per_split);
+        return MF_OK;
+      }
+    }
+  }
   if (d->upsample == 3 && ((long)(d->N / 16) * hw_src) % pl->cfg.BM) {
     // the chosen tile straddles two components: the largest built tile of the same arithmetic whose rows divide a component
     const long rows = (long)(d->N / 16) * hw_src;
